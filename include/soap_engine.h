@@ -1,0 +1,179 @@
+/*
+ * soap_engine.h -- C ABI of the MI355X halo-property engine.
+ *
+ * This is the drop-in boundary for SOAP's per-halo hot path.  One engine handle
+ * owns one GPU and replaces, for one chunk of particles, the work the reference
+ * does inside
+ *     process_halos()            SOAP/core/halo_tasks.py:276-430
+ *       process_single_halo()    SOAP/core/halo_tasks.py:23-273
+ *         SharedMesh.query_radius_periodic()   SOAP/core/shared_mesh.py:122-200
+ *         HaloProperty.calculate()             SOAP/particle_selection/<...>.py
+ *           property_calculation/<...>.py kernels
+ * and the mesh build that precedes it (SharedMesh.__init__, shared_mesh.py:11-114,
+ * called from ChunkTask.__call__, SOAP/core/chunk_tasks.py:293-304).
+ *
+ * Conventions
+ *   - plain C types only, no exceptions, no callbacks; every function returns 0 on
+ *     success and a negative code on failure (soap_engine_last_error() has the text).
+ *   - the caller keeps ownership of every buffer it passes in; the library copies
+ *     what it needs into HBM during the stage_* calls.
+ *   - a handle is not re-entrant; use one handle per GPU per process (or thread).
+ *   - unit system: lengths are COMOVING code lengths, densities are mass per comoving
+ *     length^3, velocities/masses are code units.  Physical radii (kpc apertures,
+ *     20 Mpc limit) are converted by the caller ONCE (see soap_amd/units.py).
+ */
+#ifndef SOAP_ENGINE_H
+#define SOAP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOAP_ENGINE_ABI_VERSION 1
+
+/* particle types the selections know about, in the reference's concatenation order
+ * (SO_properties.py:3520-3550).  "slot" below is the position in this list. */
+#define SOAP_NTYPES 4 /* PartType0, PartType1, PartType4, PartType5 */
+
+typedef struct soap_engine soap_engine; /* opaque */
+
+/* What HaloProperty.__init__ copies from the cellgrid
+ * (SOAP/particle_selection/halo_properties.py:8-35), already converted. */
+typedef struct soap_engine_config {
+    int32_t abi_version;    /* SOAP_ENGINE_ABI_VERSION */
+    int32_t device;         /* HIP device ordinal */
+    double boxsize;         /* comoving code length */
+    double G_eff;           /* Newton G / a : v^2 = G_eff * M / r_comoving */
+    double nu_density;      /* mean neutrino density, mass / comoving length^3 */
+    double mpc20;           /* 20 Mpc in comoving code length (SO_properties.py:150) */
+    double softening[SOAP_NTYPES]; /* comoving code length per type slot */
+    int32_t n_workgroups;   /* 0 = library default (persistent grid size) */
+    int32_t slab_capacity;  /* 0 = default; max particles in one halo's search sphere */
+} soap_engine_config;
+
+/* calculation kinds: one per HaloProperty subclass on the path */
+enum {
+    SOAP_CALC_SUBHALO = 0,         /* SubhaloProperties      subhalo_properties.py:2345 */
+    SOAP_CALC_SO_DENSITY = 1,      /* SOProperties mean/crit/BN98   SO_properties.py:3215 */
+    SOAP_CALC_SO_PHYSICAL = 2,     /* SOProperties type="physical" */
+    SOAP_CALC_SO_MULTIPLE = 3,     /* RadiusMultipleSOProperties  SO_properties.py:3797 */
+    SOAP_CALC_APERTURE_INCL = 4,   /* InclusiveSphereProperties   aperture_properties.py:4324 */
+    SOAP_CALC_APERTURE_EXCL = 5,   /* ExclusiveSphereProperties   aperture_properties.py:4247 */
+    SOAP_CALC_PROJECTED = 6        /* ProjectedApertureProperties projected_aperture_properties.py:1580 */
+};
+
+/* one entry of halo_prop_list, in the reference's list order
+ * (SOAP/compute_halo_properties.py:232-505) */
+typedef struct soap_calc_desc {
+    int32_t kind;
+    int32_t parent;              /* SO_MULTIPLE: position of the parent SO in the list;
+                                    APERTURE_EXCL / PROJECTED: position of the next-smaller
+                                    aperture of the same family (skip/copy rule,
+                                    aperture_properties.py:4082-4123), -1 = none */
+    double reference_density;    /* SO_DENSITY: threshold, mass / comoving length^3 */
+    double radius;               /* apertures, SO_PHYSICAL: comoving code length;
+                                    SO_MULTIPLE: the multiple */
+    double physical_radius_mpc;  /* HaloProperty.physical_radius_mpc converted to comoving
+                                    code length: radius the scheduler jumps to when this
+                                    calculation raises SearchRadiusTooSmallError
+                                    (halo_tasks.py:129-139, :168, :187) */
+    double prev_radius;          /* comoving radius of `parent` aperture (copy rule) */
+    int32_t virial_definition;   /* SO_properties.py:3458-3469 (concentration only then) */
+    int32_t filter_limit;        /* category filter of the calculation: minimum number of
+                                    bound particles (0 = "basic"), category_filter.py:69-106 */
+    int32_t filter_types;        /* bit mask over type slots counted by the filter */
+    int32_t reserved;
+} soap_calc_desc;
+
+/* per-halo status column */
+enum {
+    SOAP_HALO_OK = 0,
+    SOAP_HALO_NEED_LARGER_READ_RADIUS = 1, /* process_single_halo returned None
+                                              (halo_tasks.py:169-181); new radii fetched */
+    SOAP_HALO_FATAL_TOO_MANY_BOUND = -1,   /* subhalo_properties.py:2642-2646 */
+    SOAP_HALO_FATAL_SO_BEYOND_20MPC = -2,  /* SO_properties.py:150-153 */
+    SOAP_HALO_FATAL_SLAB_OVERFLOW = -3,    /* search sphere larger than slab_capacity */
+    SOAP_HALO_FATAL_RADIUS_ASSERT = -4     /* halo_tasks.py:78 */
+};
+
+/* number of fp64 output columns a calculation kind writes (fixed layout, see
+ * soap_amd/layout.py which mirrors csrc/layout.h) */
+int32_t soap_engine_calc_columns(int32_t kind);
+
+int32_t soap_engine_abi_version(void);
+const char *soap_engine_last_error(void);
+
+int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out);
+int32_t soap_engine_destroy(soap_engine *h);
+
+/*
+ * Stage one particle type of the chunk and build its cell-list mesh.
+ * Replaces share_array() + SharedMesh(comm, pos, resolution)
+ * (chunk_tasks.py:165-170, :293-304; shared_mesh.py:11-114).
+ *   type_slot      0..3  (PartType0,1,4,5)
+ *   pos, vel       [n][3] doubles, as data[ptype]["Coordinates"/"Velocities"]
+ *   mass           [n]    doubles  (Masses, or DynamicalMasses for PartType5)
+ *   grnr           [n]    GroupNr_bound, int32 or int64 (grnr_bytes = 4 or 8)
+ *   fof            [n]    FOFGroupIDs int64
+ *   resolution     mesh cells per dimension (chunk_tasks.py:299-302 computes it)
+ *   on_device      0: host pointers, 1: device (HBM) pointers on cfg.device
+ */
+int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n,
+                                    const double *pos, const double *vel, const double *mass,
+                                    const void *grnr, int32_t grnr_bytes, const int64_t *fof,
+                                    int32_t resolution, int32_t on_device);
+
+/*
+ * Stage the chunk's halo table (halo_arrays of process_halos, halo_tasks.py:276-287),
+ * in processing order (the reference sorts by nr_bound_part descending,
+ * chunk_tasks.py:118-120).  Host pointers.
+ */
+int32_t soap_engine_stage_halos(soap_engine *h, int64_t n_halo, const double *cofp /*[n][3]*/,
+                                const double *search_radius, const double *read_radius,
+                                const int64_t *index, const int32_t *is_central,
+                                const int64_t *nr_bound_part);
+
+/*
+ * process_halos(): run every calculation of `calcs` for every staged halo.
+ * target_density: minimum over the calculations' density multiples
+ * (halo_tasks.py:306-317) in mass / comoving length^3; <= 0 means None.
+ */
+int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_calcs,
+                        double target_density);
+
+/* row length of the result table of the last run (sum of calc columns) */
+int64_t soap_engine_row_columns(const soap_engine *h);
+
+/*
+ * Copy results of the last run to caller-allocated host buffers (any may be NULL):
+ *   table          [n_halo][row_columns] fp64 pre-cast values (zeros where not computed)
+ *   status         [n_halo]
+ *   search_radius, read_radius  [n_halo] updated radii (halo_tasks.py:393-402)
+ *   stats          [n_halo][4] int64: n_loop, n_sel (final sphere), n_cand (final), reserved
+ */
+int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double *search_radius,
+                          double *read_radius, int64_t *stats);
+
+/* device pointer of the result table (for the multi-GPU catalogue gather), or NULL */
+const double *soap_engine_table_device(const soap_engine *h);
+
+/*
+ * Debug/verification entry: original particle indices (positions in the staged arrays) of
+ * the particles of `type_slot` whose wrapped radius about halo row `row` satisfies
+ * r < radius (strict != 0) or r <= radius (strict == 0), optionally bound-only.
+ * Uses the same device arithmetic as the property kernels.  Returns the count (<0 on
+ * error); at most `cap` indices are written, sorted ascending.
+ */
+int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t type_slot, double radius,
+                               int32_t strict, int32_t bound_only, int64_t *out, int64_t cap);
+
+/* average duration in ms of the named internal kernel over the last run, measured with
+ * HIP events on the engine's stream ("halo", "reorder", "mesh"); <0 if unknown */
+double soap_engine_kernel_ms(const soap_engine *h, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOAP_ENGINE_H */

@@ -1,0 +1,1168 @@
+"""
+oracle/halo_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU (NumPy/SciPy, fp64) restatement of SOAP's per-halo hot path:
+particle_selection + property_calculation as driven by core/halo_tasks.py.
+It exists to *check* the HIP engine (tests/, __graft_entry__.smoke(), and the
+`cpu_baseline` leg of bench.py).  Nothing in the product path (soap_amd/) may
+import it.
+
+Parity pinning: the arithmetic kernels in here (SO radius finder, half-mass
+radius, v_max, angular momentum, dispersion matrix, mesh query) are pinned by
+ (a) golden vectors generated in the build container by running the
+     reference's own functions (tests/golden/make_golden.py, outputs committed
+     under tests/golden/*.npz), and
+ (b) the invariants the reference's own tests assert
+     (tests/test_shared_mesh.py:76-124, tests/test_half_mass_radius.py:29-38,
+      tests/test_SO_properties.py:434-446).
+Each function cites the reference file:line it follows (paths relative to the
+reference checkout, e.g. SOAP/core/halo_tasks.py).
+
+Unit convention (the reference carries `unyt` units; this restatement is
+unit-free, one fixed system, see DESIGN.md "Units"):
+  lengths      comoving code length  (a * snap_length)
+  velocities   code velocity         (snap_length / snap_time)
+  masses       code mass
+  densities    code mass / comoving code length^3
+Physical radii (kpc apertures, SO-radius multiples) are converted to comoving
+code length ONCE by `Units`, with a single explicit factor, so that membership
+counts are reproducible bit-for-bit between oracle and engine.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional
+
+import numpy as np
+from scipy.optimize import brentq
+
+# SOAP/core/halo_tasks.py:14-20
+SEARCH_RADIUS_FACTOR = 1.2
+READ_RADIUS_FACTOR = 1.5
+
+# SOAP/core/dataset_names.py:4
+PTYPES_FOR_SO_MASSES = (0, 1, 4, 5)
+# particle types the selections concatenate, in this order
+# (SO_properties.py:3520-3550, aperture_properties.py:3995-4005)
+PTYPES = (0, 1, 4, 5)
+
+
+class SearchRadiusTooSmallError(Exception):
+    """SOAP/particle_selection/halo_properties.py:4-5"""
+
+
+# --------------------------------------------------------------------------
+# units / snapshot scalars (what HaloProperty.__init__ copies from the cellgrid,
+# SOAP/particle_selection/halo_properties.py:8-35)
+# --------------------------------------------------------------------------
+@dataclasses.dataclass
+class Units:
+    """All scalars the hot path needs, in the fixed unit system above."""
+
+    a: float  # expansion factor
+    boxsize: float  # comoving code length
+    critical_density: float  # PHYSICAL code density (header value)
+    mean_density: float  # PHYSICAL code density
+    kpc: float  # one physical kpc in PHYSICAL code length (kpc_cm / U_L)
+    G: float  # Newton's G in physical code units
+    softening: Dict[int, float]  # per ptype, PHYSICAL code length
+    nu_density: float = 0.0  # PHYSICAL code density of the nu background
+    virBN98: float = 0.0
+
+    # --- the single explicit conversions (DESIGN.md "Units") ---
+    def kpc_to_comoving(self, r_kpc: float) -> float:
+        return r_kpc * self.kpc / self.a
+
+    def mpc_to_comoving(self, r_mpc: float) -> float:
+        return r_mpc * (1000.0 * self.kpc) / self.a
+
+    def density_to_comoving(self, rho_phys: float) -> float:
+        return rho_phys * self.a**3
+
+    def softening_comoving(self, ptype: int) -> float:
+        return self.softening[ptype] / self.a
+
+    @property
+    def G_eff(self) -> float:
+        # v^2 = G M / (a r_comoving)
+        return self.G / self.a
+
+    @property
+    def nu_density_comoving(self) -> float:
+        return self.nu_density * self.a**3
+
+
+def flamingo_like_units(boxsize: float = 100.0) -> Units:
+    """
+    The concrete consistent scalar set of the reference's dummy snapshot
+    (tests/dummy_halo_generator.py:40-126, :416-496): FLAMINGO header at z=0.3.
+    """
+    a = 0.76923077
+    U_L = 3.08567758e24
+    U_M = 1.98841e43
+    U_t = 3.08567758e19
+    rho_crit = 17.58736923
+    Omega_m = 0.304611
+    Omega_k = 2.5212783e-09
+    Omega_lambda = 0.693922
+    G_cgs = 6.6743e-08
+    kpc_cm = 3.08567758e21
+    soft = min(0.0446 * a, 0.0114)
+    bnx = -(Omega_k / a**2 + Omega_lambda) / (
+        Omega_k / a**2 + Omega_m / a**3 + Omega_lambda
+    )
+    virBN98 = 18.0 * np.pi**2 + 82.0 * bnx - 39.0 * bnx**2
+    return Units(
+        a=a,
+        boxsize=boxsize,
+        critical_density=rho_crit,
+        mean_density=rho_crit * Omega_m,
+        kpc=kpc_cm / U_L,
+        G=G_cgs * U_M * U_t**2 / U_L**3,
+        softening={0: soft, 1: soft, 4: soft, 5: soft},
+        nu_density=0.0,
+        virBN98=float(virBN98),
+    )
+
+
+# --------------------------------------------------------------------------
+# L0 kernels
+# --------------------------------------------------------------------------
+def cumulative_mass_intersection(r, rho_dim, slope_dim):
+    """SO_properties.py:50-77"""
+    return 4.0 * np.pi / 3.0 * rho_dim * r**3 - slope_dim * r + slope_dim - 1.0
+
+
+def find_SO_radius_and_mass(
+    ordered_radius, density, cumulative_mass, reference_density, mpc20=np.inf
+):
+    """
+    SO_properties.py:80-217.  `mpc20` is 20 Mpc in the radius array's unit
+    (the RuntimeError branch, :150-153, :190-193).
+    Returns (SO_r, SO_mass, SO_volume).
+    """
+    above_mask = density > reference_density
+    if above_mask[0]:
+        below_mask = ~above_mask
+        i = int(np.argmax(below_mask))
+        if i == 0:
+            if ordered_radius[-1] > mpc20:
+                raise RuntimeError(
+                    "Cannot find SO radius, but search radius is already larger than 20 Mpc!"
+                )
+            raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
+    else:
+        ipos = 0
+        while ipos < len(cumulative_mass) and cumulative_mass[ipos] < 0.0:
+            ipos += 1
+        if ipos == len(cumulative_mass):
+            raise RuntimeError("Should never happen!")
+        SO_r = np.sqrt(
+            0.75 * cumulative_mass[ipos] / (np.pi * ordered_radius[ipos] * reference_density)
+        )
+        SO_mass = cumulative_mass[ipos] * SO_r / ordered_radius[ipos]
+        return SO_r, SO_mass, 4.0 * np.pi / 3.0 * SO_r**3
+
+    r1 = ordered_radius[i - 1]
+    r2 = ordered_radius[i]
+    M1 = cumulative_mass[i - 1]
+    M2 = cumulative_mass[i]
+    while r1 == r2 or (above_mask[i - 1] == above_mask[i]):
+        i += 1
+        if i >= len(density):
+            if ordered_radius[-1] > mpc20:
+                raise RuntimeError(
+                    "Cannot find SO radius, but search radius is already larger than 20 Mpc!"
+                )
+            raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
+        r1 = r2
+        r2 = ordered_radius[i]
+        M1 = M2
+        M2 = cumulative_mass[i]
+
+    rho_dim = reference_density * r1**3 / M1
+    slope_dim = (M2 - M1) / (r2 - r1) * (r1 / M1)
+    SO_r = r1 * brentq(cumulative_mass_intersection, 1.0, r2 / r1, args=(rho_dim, slope_dim))
+    SO_volume = 4.0 / 3.0 * np.pi * SO_r**3
+    SO_mass = SO_volume * reference_density
+    return SO_r, SO_mass, SO_volume
+
+
+def get_half_weight_radius(radius, weights, total_weight):
+    """half_mass_radius.py:16-97"""
+    if total_weight == 0.0 or len(weights) < 1:
+        return 0.0
+    target_weight = 0.5 * total_weight
+    isort = np.argsort(radius)
+    sorted_radius = radius[isort]
+    cumulative_weights = weights[isort].cumsum(dtype=np.float64)
+    if cumulative_weights[-1] < 0.998 * total_weight:
+        raise RuntimeError("Weights sum up to less than the given total weight value")
+    ihalf = int(np.argmax(cumulative_weights >= target_weight))
+    if ihalf == 0:
+        rmin = 0.0
+        WeightMin = 0.0
+    else:
+        rmin = sorted_radius[ihalf - 1]
+        WeightMin = cumulative_weights[ihalf - 1]
+    rmax = sorted_radius[ihalf]
+    WeightMax = cumulative_weights[ihalf]
+    if WeightMin == WeightMax:
+        half_weight_radius = 0.5 * (rmin + rmax)
+    else:
+        half_weight_radius = rmin + (target_weight - WeightMin) / (WeightMax - WeightMin) * (
+            rmax - rmin
+        )
+    if half_weight_radius > sorted_radius[-1]:
+        raise RuntimeError("Half weight radius larger than input radii")
+    return float(half_weight_radius)
+
+
+def get_vmax(mass, radius, G, nskip=0):
+    """kinematic_properties.py:555-593.  Returns (r_vmax, vmax)."""
+    isort = np.argsort(radius)
+    ordered_radius = radius[isort]
+    cumulative_mass = mass[isort].cumsum()
+    nskip = max(nskip, int(np.argmin(np.isclose(ordered_radius, 0.0))))
+    ordered_radius = ordered_radius[nskip:]
+    if len(ordered_radius) == 0 or ordered_radius[0] == 0:
+        return 0.0, 0.0
+    cumulative_mass = cumulative_mass[nskip:]
+    v_over_G = cumulative_mass / ordered_radius
+    imax = int(np.argmax(v_over_G))
+    return float(ordered_radius[imax]), float(np.sqrt(v_over_G[imax] * G))
+
+
+def get_angular_momentum(mass, position, velocity, ref_velocity=None):
+    """kinematic_properties.py:222-263 (also :325-356 for the mass-weighted path)"""
+    vrel = velocity if ref_velocity is None else velocity - ref_velocity[None, :]
+    return (mass[:, None] * np.cross(position, vrel)).sum(axis=0)
+
+
+def get_velocity_dispersion_matrix(mass_fraction, velocity, ref_velocity):
+    """
+    kinematic_properties.py:91-127.  The reference accumulates into a float32
+    buffer (:117); we return (fp64 pre-cast values, float32 stored values).
+    """
+    vrel = velocity - ref_velocity[None, :]
+    r64 = np.array(
+        [
+            (mass_fraction * vrel[:, 0] * vrel[:, 0]).sum(),
+            (mass_fraction * vrel[:, 1] * vrel[:, 1]).sum(),
+            (mass_fraction * vrel[:, 2] * vrel[:, 2]).sum(),
+            (mass_fraction * vrel[:, 0] * vrel[:, 1]).sum(),
+            (mass_fraction * vrel[:, 0] * vrel[:, 2]).sum(),
+            (mass_fraction * vrel[:, 1] * vrel[:, 2]).sum(),
+        ]
+    )
+    r32 = np.zeros(6, dtype=np.float32)
+    r32 += r64
+    return r64, r32
+
+
+def concentration_from_R1(R1):
+    """SO_properties.py:2725-2736; result is float32 in the reference."""
+    polynomial = [-79.71, -222.46, -250.14, -140.17, -43.59, -5.07]
+    c = 0
+    for i, b in enumerate(polynomial[::-1]):
+        c += b * np.log10(R1) ** i
+    c = max(min(c, 3), 0)
+    return float(10**c)
+
+
+# --------------------------------------------------------------------------
+# mesh (SOAP/core/shared_mesh.py)
+# --------------------------------------------------------------------------
+class Mesh:
+    """shared_mesh.py:11-114 (single process: no MPI reductions)."""
+
+    def __init__(self, pos: np.ndarray, resolution: int):
+        self.empty = pos.shape[0] == 0
+        if self.empty:
+            return
+        self.pos_min = np.amin(pos, axis=0)
+        self.pos_max = np.amax(pos, axis=0)
+        for i in range(3):
+            if self.pos_min[i] == self.pos_max[i]:
+                self.pos_max[i] = self.pos_min[i] + 1.0
+        self.resolution = int(resolution)
+        nr_cells = self.resolution**3
+        self.cell_size = (self.pos_max - self.pos_min) / self.resolution
+        cell_idx = np.floor((pos - self.pos_min[None, :]) / self.cell_size[None, :]).astype(
+            np.int32
+        )
+        cell_idx = np.clip(cell_idx, 0, self.resolution - 1)
+        cell_idx = (
+            cell_idx[:, 0]
+            + self.resolution * cell_idx[:, 1]
+            + (self.resolution**2) * cell_idx[:, 2]
+        )
+        self.cell_count = np.bincount(cell_idx, minlength=nr_cells)
+        self.cell_offset = np.zeros_like(self.cell_count)
+        if nr_cells > 1:
+            self.cell_offset[1:] = np.cumsum(self.cell_count[:-1])
+        # the reference uses an MPI parallel sort (shared_mesh.py:105); ordering
+        # within a cell only affects summation order -> use a stable sort.
+        self.sort_idx = np.argsort(cell_idx, kind="stable")
+
+    def cell_coords(self, centre, radius, boxsize):
+        """shared_mesh.py:146-179 -> sorted lists of cell coordinates per dimension."""
+        coords = [set() for _ in range(3)]
+        for dim in (0, 1, 2):
+            min_copy_nr = 0
+            while centre[dim] + (min_copy_nr - 1) * boxsize + radius >= self.pos_min[dim]:
+                min_copy_nr -= 1
+            max_copy_nr = 0
+            while centre[dim] + (max_copy_nr + 1) * boxsize - radius <= self.pos_max[dim]:
+                max_copy_nr += 1
+            for copy_nr in range(min_copy_nr, max_copy_nr + 1, 1):
+                min_coord = max(self.pos_min[dim], centre[dim] + copy_nr * boxsize - radius)
+                min_idx = int(np.floor((min_coord - self.pos_min[dim]) / self.cell_size[dim]))
+                max_coord = min(self.pos_max[dim], centre[dim] + copy_nr * boxsize + radius)
+                max_idx = int(np.floor((max_coord - self.pos_min[dim]) / self.cell_size[dim]))
+                for cell_nr in range(min_idx, max_idx + 1):
+                    if cell_nr >= 0 and cell_nr < self.resolution:
+                        coords[dim].add(cell_nr)
+        # Python set iteration order is an implementation detail; we fix it to
+        # ascending (order only affects summation rounding).
+        return [sorted(c) for c in coords]
+
+    def query_radius_periodic(self, centre, radius, pos, boxsize, return_ncand=False):
+        """shared_mesh.py:122-200"""
+        if self.empty:
+            out = np.ndarray(0, dtype=np.int64)
+            return (out, 0) if return_ncand else out
+        cc = self.cell_coords(centre, radius, boxsize)
+        idx = []
+        ncand = 0
+        res = self.resolution
+        r2max = radius * radius
+        for k in cc[2]:
+            for j in cc[1]:
+                # the i-cells of one (j,k) row are consecutive in memory; evaluate the
+                # row cell by cell exactly as the reference does.
+                for i in cc[0]:
+                    cell_nr = i + res * j + (res**2) * k
+                    start = self.cell_offset[cell_nr]
+                    count = self.cell_count[cell_nr]
+                    if count > 0:
+                        ncand += int(count)
+                        idx_in_cell = self.sort_idx[start : start + count]
+                        dr = pos[idx_in_cell, :] - centre[None, :]
+                        dr[dr > 0.5 * boxsize] -= boxsize
+                        dr[dr < -0.5 * boxsize] += boxsize
+                        r2 = np.sum(dr**2, axis=1)
+                        keep = r2 <= r2max
+                        if np.sum(keep) > 0:
+                            idx.append(idx_in_cell[keep])
+        out = np.concatenate(idx) if len(idx) > 0 else np.ndarray(0, dtype=np.int64)
+        return (out, ncand) if return_ncand else out
+
+
+def mesh_resolution(nr_parts: int) -> int:
+    """SOAP/core/chunk_tasks.py:299-302"""
+    resolution = int((nr_parts / 1000) ** (1.0 / 3.0))
+    return min(max(resolution, 1), 256)
+
+
+# --------------------------------------------------------------------------
+# category filter (SOAP/core/category_filter.py:69-106)
+# --------------------------------------------------------------------------
+DEFAULT_FILTERS = {
+    "general": dict(limit=100, properties=("Ndm", "Ngas", "Nstar", "Nbh")),
+    "dm": dict(limit=100, properties=("Ndm",)),
+    "gas": dict(limit=100, properties=("Ngas",)),
+    "star": dict(limit=100, properties=("Nstar",)),
+    "baryon": dict(limit=100, properties=("Ngas", "Nstar")),
+}
+
+
+def get_do_calculation(filters, counts, dmo):
+    """counts: dict Ndm/Ngas/Nstar/Nbh of the bound subhalo."""
+    do_calculation = {"basic": True}
+    c = dict(counts)
+    if dmo:
+        c["Ngas"] = 0
+        c["Nstar"] = 0
+        c["Nbh"] = 0
+    for name, info in filters.items():
+        v = 0
+        for p in info["properties"]:
+            v += c[p]
+        do_calculation[name] = v >= info["limit"]
+    return do_calculation
+
+
+# --------------------------------------------------------------------------
+# per-halo particle container helpers
+# --------------------------------------------------------------------------
+def _concat_types(data, fields):
+    out = {f: [] for f in fields}
+    types = []
+    for ptype in PTYPES:
+        if ptype not in data:
+            continue
+        d = data[ptype]
+        n = d["Coordinates"].shape[0]
+        for f in fields:
+            out[f].append(d[f])
+        types.append(ptype * np.ones(n, dtype=np.int32))
+    res = {f: np.concatenate(v) if len(v) else np.zeros(0) for f, v in out.items()}
+    res["types"] = np.concatenate(types) if len(types) else np.zeros(0, dtype=np.int32)
+    return res
+
+
+# Output bookkeeping: each calculation fills halo_result[f"{group}/{key}"] with a
+# `Value(raw, stored)`; raw = fp64 pre-cast value in engine units, stored = what
+# the reference would put in its zero-initialised table-dtype array
+# (SO_properties.py:3600-3620, :3682-3699): float32/float64/uint32.
+@dataclasses.dataclass
+class Value:
+    raw: np.ndarray
+    stored: np.ndarray
+
+
+# key -> (shape, dtype).  Mirrors the rows of SOAP/property_table.py listed in
+# SURVEY.md section 8(a) a22.  Units/a-exponents live in soap_amd/property_table.py.
+SCHEMA = {
+    "r": (1, np.float32),
+    "Mtot": (1, np.float32),
+    "Mdm": (1, np.float32),
+    "Mgas": (1, np.float32),
+    "Mstar": (1, np.float32),
+    "Mbh_dynamical": (1, np.float32),
+    "Ndm": (1, np.uint32),
+    "Ngas": (1, np.uint32),
+    "Nstar": (1, np.uint32),
+    "Nbh": (1, np.uint32),
+    "com": (3, np.float64),
+    "vcom": (3, np.float32),
+    "Ldm": (3, np.float32),
+    "veldisp_matrix_dm": (6, np.float32),
+    "proj_veldisp_dm": (1, np.float32),
+    "HalfMassRadiusDM": (1, np.float32),
+    "HalfMassRadiusTot": (1, np.float32),
+    "EncloseRadius": (1, np.float32),
+    "Vmax_soft": (1, np.float32),
+    "R_vmax_soft": (1, np.float32),
+    "Vmax_unsoft": (1, np.float32),
+    "R_vmax_unsoft": (1, np.float32),
+    "spin_parameter": (1, np.float32),
+    "concentration_soft": (1, np.float32),
+    "concentration_unsoft": (1, np.float32),
+    "Mfrac_satellites": (1, np.float32),
+    "Mfrac_external": (1, np.float32),
+}
+
+
+def _store(result, group, key, val):
+    shape, dtype = SCHEMA[key]
+    if val is None:
+        raw = np.zeros(shape, dtype=np.float64)
+    else:
+        raw = np.atleast_1d(np.asarray(val, dtype=np.float64)).copy()
+        assert raw.shape == (shape,), f"{key}: wrong shape {raw.shape}"
+        assert np.max(np.abs(raw)) < float("inf")
+    stored = np.zeros(shape, dtype=dtype)
+    if np.issubdtype(dtype, np.integer):
+        stored[:] = raw.astype(dtype)
+    else:
+        stored += raw  # zero-initialised table-dtype array += value (cast once)
+    result[f"{group}/{key}"] = Value(raw, stored)
+
+
+# --------------------------------------------------------------------------
+# BoundSubhalo  (subhalo_properties.py)
+# --------------------------------------------------------------------------
+class SubhaloProperties:
+    """subhalo_properties.py:128-164, :206-376, :798-846, :982-1073, :1272-1366,
+    :2265-2343, :2587-2740 -- DMO/basic property subset."""
+
+    name = "bound_subhalo"
+    group_name = "BoundSubhalo"
+    halo_filter = "basic"
+    physical_radius_mpc = 0.0
+    mean_density_multiple = None
+    critical_density_multiple = None
+    property_list = [
+        "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
+        "com", "vcom", "Ldm", "Vmax_unsoft", "Vmax_soft", "R_vmax_unsoft", "spin_parameter",
+        "HalfMassRadiusTot", "HalfMassRadiusDM", "veldisp_matrix_dm", "EncloseRadius",
+    ]  # fmt: skip
+
+    def __init__(self, units: Units, filters=DEFAULT_FILTERS, dmo=True):
+        self.units = units
+        self.filters = filters
+        self.dmo = dmo
+
+    def calculate(self, input_halo, search_radius, data, halo_result):
+        u = self.units
+        centre = input_halo["cofp"]
+        index = input_halo["index"]
+        mass, position, radius, velocity, types, softening = [], [], [], [], [], []
+        for ptype in PTYPES:
+            if ptype not in data:
+                continue
+            d = data[ptype]
+            in_halo = d["GroupNr_bound"] == index
+            mass.append(d["Masses"][in_halo])
+            pos = d["Coordinates"][in_halo, :] - centre[None, :]
+            position.append(pos)
+            r = np.sqrt(pos[:, 0] ** 2 + pos[:, 1] ** 2 + pos[:, 2] ** 2)
+            radius.append(r)
+            velocity.append(d["Velocities"][in_halo, :])
+            types.append(ptype * np.ones(r.shape, dtype=np.int32))
+            softening.append(np.ones(r.shape, dtype=np.float64) * u.softening_comoving(ptype))
+        mass = np.concatenate(mass)
+        position = np.concatenate(position)
+        radius = np.concatenate(radius)
+        velocity = np.concatenate(velocity)
+        types = np.concatenate(types)
+        softening = np.concatenate(softening)
+
+        N = {t: int((types == t).sum()) for t in PTYPES}
+        counts = {"Ngas": N[0], "Ndm": N[1], "Nstar": N[4], "Nbh": N[5]}
+        Ntot = N[0] + N[1] + N[4] + N[5]
+        Nexpected = int(input_halo["nr_bound_part"])
+        if Ntot < Nexpected:
+            raise SearchRadiusTooSmallError(
+                "Search radius does not contain expected number of particles!"
+            )
+        elif Ntot > Nexpected:
+            raise RuntimeError(f"Found more particles than expected for halo {index}")
+
+        g = self.group_name
+        out = {}
+        Mtot = mass.sum()
+        out["Mtot"] = Mtot
+        M_t = {t: mass[types == t].sum() for t in PTYPES}
+        out["Mgas"], out["Mdm"], out["Mstar"], out["Mbh_dynamical"] = M_t[0], M_t[1], M_t[4], M_t[5]
+        out["Ngas"], out["Ndm"], out["Nstar"], out["Nbh"] = N[0], N[1], N[4], N[5]
+        vcom = None
+        if Mtot != 0:
+            frac = mass / Mtot
+            out["com"] = ((frac[:, None] * position).sum(axis=0) + centre) % u.boxsize
+            vcom = (frac[:, None] * velocity).sum(axis=0)
+            out["vcom"] = vcom
+        dm = types == 1
+        if M_t[1] != 0:
+            fdm = mass[dm] / M_t[1]
+            vcom_dm = (fdm[:, None] * velocity[dm]).sum(axis=0)
+            out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
+            out["veldisp_matrix_dm"] = get_velocity_dispersion_matrix(fdm, velocity[dm], vcom_dm)[0]
+        if Mtot != 0:
+            r_u, v_u = get_vmax(mass, radius, u.G_eff, nskip=1)
+            out["R_vmax_unsoft"], out["Vmax_unsoft"] = r_u, v_u
+            soft_r = np.maximum(softening, radius)
+            r_s, v_s = get_vmax(mass, soft_r, u.G_eff)
+            out["Vmax_soft"] = v_s
+            # spin (subhalo_properties.py:1046-1073)
+            if r_s > 0 and v_s > 0:
+                mask = radius <= r_s
+                vrel = velocity[mask, :] - vcom[None, :]
+                Ltot = np.linalg.norm(
+                    (mass[mask, None] * np.cross(position[mask, :], vrel)).sum(axis=0)
+                )
+                M_r = mass[mask].sum()
+                if M_r > 0:
+                    out["spin_parameter"] = Ltot / (np.sqrt(2.0) * M_r * v_s * r_s)
+            out["EncloseRadius"] = np.max(radius)
+        out["HalfMassRadiusTot"] = get_half_weight_radius(radius, mass, Mtot)
+        out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
+
+        for key in self.property_list:
+            _store(halo_result, g, key, out.get(key))
+        halo_result["_counts"] = counts
+
+
+# --------------------------------------------------------------------------
+# SO  (SO_properties.py)
+# --------------------------------------------------------------------------
+class SOProperties:
+    """SO_properties.py:313-513, :532-692, :857-913, :2725-2765, :3370-3742."""
+
+    property_list = [
+        "r", "Mtot", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Vmax_soft", "R_vmax_soft",
+        "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
+        "spin_parameter", "concentration_unsoft", "concentration_soft",
+    ]  # fmt: skip
+
+    def __init__(self, units: Units, SOval: float, type: str = "mean",
+                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
+        if type not in ["mean", "crit", "physical", "BN98"]:
+            raise AttributeError(f"Unknown SO type: {type}!")
+        self.units = units
+        self.type = type
+        self.halo_filter = halo_filter
+        self.filters = filters
+        self.dmo = dmo
+        # SO_properties.py:3453-3471
+        self.mean_density_multiple = 1000.0
+        self.critical_density_multiple = 1000.0
+        self.physical_radius_mpc = 0.0
+        self.virial_definition = False
+        if type == "mean":
+            self.mean_density_multiple = SOval
+            self.virial_definition = SOval == 200
+        elif type == "crit":
+            self.critical_density_multiple = SOval
+            self.virial_definition = SOval == 200
+        elif type == "BN98":
+            self.critical_density_multiple = units.virBN98
+            self.virial_definition = True
+        elif type == "physical":
+            self.physical_radius_mpc = 0.001 * SOval
+        if type in ["mean", "crit"]:
+            self.name = f"SO_{SOval:.0f}_{type}"
+        elif type == "physical":
+            self.name = f"SO_{SOval:.0f}_kpc"
+        else:
+            self.name = "SO_BN98"
+        # SO_properties.py:3490-3509 (physical density), converted once to comoving
+        if type == "crit":
+            rho = self.critical_density_multiple * units.critical_density
+            self.SO_name = f"{self.critical_density_multiple:.0f}_crit"
+        elif type == "mean":
+            rho = self.mean_density_multiple * units.mean_density
+            self.SO_name = f"{self.mean_density_multiple:.0f}_mean"
+        elif type == "physical":
+            rho = 0.0
+            self.SO_name = f"{1000. * self.physical_radius_mpc:.0f}_kpc"
+        else:
+            rho = self.critical_density_multiple * units.critical_density
+            self.SO_name = "BN98"
+        self.reference_density = units.density_to_comoving(rho)
+        self.group_name = f"SO/{self.SO_name}"
+
+    # radius (comoving code length) used when reference_density == 0
+    def physical_radius_comoving(self):
+        return self.units.mpc_to_comoving(self.physical_radius_mpc)
+
+    def calculate(self, input_halo, search_radius, data, halo_result):
+        u = self.units
+        g = self.group_name
+        out = {}
+        do_calc = get_do_calculation(self.filters, halo_result["_counts"], self.dmo)
+        if input_halo["is_central"] and do_calc[self.halo_filter]:
+            out = self._calculate(input_halo, search_radius, data)
+        for key in self.property_list:
+            _store(halo_result, g, key, out.get(key))
+
+    def _calculate(self, input_halo, search_radius, data):
+        u = self.units
+        centre = input_halo["cofp"]
+        index = input_halo["index"]
+        # compute_basics (SO_properties.py:313-354)
+        mass, radius, position, velocity, types, groupnr, fofid, softening = ([] for _ in range(8))
+        for ptype in PTYPES:
+            if ptype not in data:
+                continue
+            d = data[ptype]
+            mass.append(d["Masses"])
+            pos = d["Coordinates"] - centre[None, :]
+            position.append(pos)
+            r = np.sqrt(np.sum(pos**2, axis=1))
+            radius.append(r)
+            velocity.append(d["Velocities"])
+            types.append(ptype * np.ones(r.shape, dtype=np.int32))
+            groupnr.append(d["GroupNr_bound"])
+            fofid.append(d["FOFGroupIDs"])
+            softening.append(np.ones(r.shape, dtype=np.float64) * u.softening_comoving(ptype))
+        mass = np.concatenate(mass)
+        radius = np.concatenate(radius)
+        position = np.concatenate(position)
+        velocity = np.concatenate(velocity)
+        types = np.concatenate(types)
+        groupnr = np.concatenate(groupnr)
+        fofid = np.concatenate(fofid)
+        softening = np.concatenate(softening)
+
+        # compute_SO_radius_and_mass (SO_properties.py:356-513), no nu particles
+        reference_density = self.reference_density
+        physical_radius = self.physical_radius_comoving()
+        if len(radius) == 0:
+            return {}  # reference would fail on order[0]; nothing in the sphere -> zeros
+        order = np.argsort(radius)
+        ordered_radius = radius[order]
+        cumulative_mass = np.cumsum(mass[order], dtype=np.float64).astype(mass.dtype)
+        cumulative_mass += u.nu_density_comoving * 4.0 / 3.0 * np.pi * ordered_radius**3
+        fof0 = fofid[order[0]]
+        nskip = max(1, int(np.argmax(ordered_radius > 0.0)))
+        ordered_radius = ordered_radius[nskip:]
+        cumulative_mass = cumulative_mass[nskip:]
+        nr_parts = len(ordered_radius)
+        density = cumulative_mass / (4.0 / 3.0 * np.pi * ordered_radius**3)
+
+        SO_r = SO_mass = None
+        if reference_density > 0:
+            if nr_parts > 0:
+                try:
+                    SO_r, SO_mass, SO_volume = find_SO_radius_and_mass(
+                        ordered_radius, density, cumulative_mass, reference_density,
+                        mpc20=u.mpc_to_comoving(20.0),
+                    )  # fmt: skip
+                except SearchRadiusTooSmallError:
+                    raise SearchRadiusTooSmallError("SO radius multiple was too small!")
+        elif physical_radius > 0:
+            SO_r = physical_radius
+            SO_volume = 4.0 * np.pi / 3.0 * SO_r**3
+            if nr_parts > 0:
+                outside_radius = ordered_radius > SO_r
+                if not np.any(outside_radius):
+                    SO_mass = cumulative_mass[-1]
+                else:
+                    i = int(np.argmax(outside_radius))
+                    if i == 0:
+                        SO_mass = cumulative_mass[i]
+                    else:
+                        r1 = ordered_radius[i - 1]
+                        r2 = ordered_radius[i]
+                        M1 = cumulative_mass[i - 1]
+                        M2 = cumulative_mass[i]
+                        SO_mass = M1 + (SO_r - r1) / (r2 - r1) * (M2 - M1)
+        # documented divergence (SURVEY 8a pitfall 7): undefined SO_r/SO_mass -> no SO
+        if SO_r is None or SO_mass is None:
+            return {}
+        SO_exists = SO_r > 0 and SO_mass > 0
+        if not SO_exists:
+            return {}
+
+        is_sat = (groupnr >= 0) & (groupnr != index) & (fofid == fof0)
+        is_ext = (groupnr >= 0) & (groupnr != index) & (fofid != fof0)
+
+        sel = radius < SO_r
+        N = {t: int((radius[types == t] < SO_r).sum()) for t in PTYPES}
+        mass = mass[sel]
+        radius = radius[sel]
+        position = position[sel]
+        velocity = velocity[sel]
+        types = types[sel]
+        is_sat = is_sat[sel]
+        is_ext = is_ext[sel]
+        softening = softening[sel]
+
+        out = {"r": SO_r, "Mtot": SO_mass}
+        out["Ngas"], out["Ndm"], out["Nstar"], out["Nbh"] = N[0], N[1], N[4], N[5]
+        Mtotpart = mass.sum()
+        frac = mass / Mtotpart if Mtotpart != 0 else None
+        with np.errstate(all="ignore"):
+            if Mtotpart == 0:
+                frac = mass * np.nan
+        out["com"] = ((frac[:, None] * position).sum(axis=0) + centre) % u.boxsize
+        vcom = (frac[:, None] * velocity).sum(axis=0)
+        out["vcom"] = vcom
+        if Mtotpart != 0:
+            soft_r = np.maximum(softening, radius)
+            r_s, v_s = get_vmax(mass, soft_r, u.G_eff)
+            out["R_vmax_soft"], out["Vmax_soft"] = r_s, v_s
+            if v_s > 0:
+                vrel = velocity - vcom[None, :]
+                Ltot = np.linalg.norm((mass[:, None] * np.cross(position, vrel)).sum(axis=0))
+                out["spin_parameter"] = Ltot / (np.sqrt(2.0) * Mtotpart * SO_r * v_s)
+        out["Mfrac_satellites"] = mass[is_sat].sum() / SO_mass
+        out["Mfrac_external"] = mass[is_ext].sum() / SO_mass
+        M_t = {t: mass[types == t].sum() for t in PTYPES}
+        out["Mgas"], out["Mdm"], out["Mstar"], out["Mbh_dynamical"] = M_t[0], M_t[1], M_t[4], M_t[5]
+        dm = types == 1
+        if M_t[1] != 0:
+            fdm = mass[dm] / M_t[1]
+            vcom_dm = (fdm[:, None] * velocity[dm]).sum(axis=0)
+            out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
+        if self.virial_definition:
+            for key, rr in (("concentration_unsoft", radius),
+                            ("concentration_soft", np.maximum(softening, radius))):  # fmt: skip
+                if rr.shape[0] < 10:
+                    continue
+                # calculate_concentration (SO_properties.py:2738-2753), no nu particles
+                R1 = np.sum(mass * rr)
+                missed_mass = SO_mass - np.sum(mass)
+                R1 += np.pi * u.nu_density_comoving * SO_r**4
+                missed_mass -= u.nu_density_comoving * 4.0 / 3.0 * np.pi * SO_r**3
+                R1 += missed_mass * SO_r
+                R1 /= SO_r * SO_mass
+                out[key] = concentration_from_R1(R1)
+        return out
+
+
+class RadiusMultipleSOProperties(SOProperties):
+    """SO_properties.py:3797-3926"""
+
+    def __init__(self, units, SOval, multiple, type="mean", **kw):
+        if type not in ["mean", "crit"]:
+            raise AttributeError("radius multiples only for type mean or crit")
+        super().__init__(units, 0, "physical", **kw)
+        self.SO_name = f"{multiple:.0f}xR_{SOval:.0f}_{type}"
+        self.group_name = f"SO/{self.SO_name}"
+        self.name = f"SO_{self.SO_name}"
+        self.requested_type = type
+        self.requested_SOval = SOval
+        self.multiple = multiple
+        self._radius_comoving = 0.0
+
+    def physical_radius_comoving(self):
+        return self._radius_comoving
+
+    def calculate(self, input_halo, search_radius, data, halo_result):
+        key = f"SO/{self.requested_SOval:.0f}_{self.requested_type}/r"
+        if key not in halo_result:
+            raise RuntimeError(f"Trying to obtain {key}, but it has not been calculated!")
+        r32 = halo_result[key].stored[0]  # float32, comoving code length
+        # :3917  physical_radius_mpc = multiple * R.to("Mpc").value  (float64 arithmetic)
+        self._radius_comoving = self.multiple * float(r32)
+        self.physical_radius_mpc = self._radius_comoving * self.units.a / (1000.0 * self.units.kpc)
+        # :3920  float32 array * python float stays float32 (NumPy>=2 promotion)
+        if np.float32(self.multiple) * r32 > search_radius:
+            raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
+        super().calculate(input_halo, search_radius, data, halo_result)
+
+
+# --------------------------------------------------------------------------
+# spherical apertures (aperture_properties.py)
+# --------------------------------------------------------------------------
+class ApertureProperties:
+    """aperture_properties.py:270-317, :373-539, :1099-1126, :1232-1281, :3469-3577,
+    :3879-4244 -- DMO/basic property subset."""
+
+    property_list = [
+        "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
+        "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
+    ]  # fmt: skip
+
+    def __init__(self, units: Units, radius_kpc: float, inclusive: bool, all_radii_kpc=None,
+                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
+        self.units = units
+        self.aperture_physical_radius_kpc = radius_kpc
+        self.inclusive = inclusive
+        self.all_radii_kpc = list(all_radii_kpc) if all_radii_kpc is not None else [radius_kpc]
+        self.halo_filter = halo_filter
+        self.filters = filters
+        self.dmo = dmo
+        self.physical_radius_mpc = 0.001 * radius_kpc
+        self.mean_density_multiple = None
+        self.critical_density_multiple = None
+        aperture_name = f"{1000*radius_kpc:.0f}pc" if radius_kpc < 1 else f"{radius_kpc:.0f}kpc"
+        if inclusive:
+            self.name = f"inclusive_sphere_{aperture_name}"
+            self.group_name = f"InclusiveSphere/{aperture_name}"
+        else:
+            self.name = f"exclusive_sphere_{aperture_name}"
+            self.group_name = f"ExclusiveSphere/{aperture_name}"
+
+    def calculate(self, input_halo, search_radius, data, halo_result):
+        u = self.units
+        g = self.group_name
+        do_calc = get_do_calculation(self.filters, halo_result["_counts"], self.dmo)
+        out = {}
+        copied = None
+        skip = False
+        # skip/copy rule (aperture_properties.py:4082-4123)
+        i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc)
+        if i_radius != 0 and ("BoundSubhalo/EncloseRadius" in halo_result):
+            r_enclose = float(halo_result["BoundSubhalo/EncloseRadius"].stored[0])  # float32
+            r_previous_kpc = self.all_radii_kpc[i_radius - 1]
+            if u.kpc_to_comoving(r_previous_kpc) > r_enclose:
+                skip = True
+                if (not self.inclusive) and do_calc[self.halo_filter]:
+                    prev = (f"{1000*r_previous_kpc:.0f}pc" if r_previous_kpc < 1
+                            else f"{r_previous_kpc:.0f}kpc")  # fmt: skip
+                    copied = f"ExclusiveSphere/{prev}"
+        if do_calc[self.halo_filter] and not skip:
+            aperture_radius = u.kpc_to_comoving(self.aperture_physical_radius_kpc)
+            if search_radius < aperture_radius:
+                raise SearchRadiusTooSmallError("Search radius is smaller than aperture")
+            out = self._calculate(input_halo, aperture_radius, data)
+        for key in self.property_list:
+            if copied is not None:
+                pv = halo_result[f"{copied}/{key}"]
+                halo_result[f"{g}/{key}"] = Value(pv.raw.copy(), pv.stored.copy())
+            else:
+                _store(halo_result, g, key, out.get(key))
+
+    def _calculate(self, input_halo, aperture_radius, data):
+        u = self.units
+        centre = input_halo["cofp"]
+        index = input_halo["index"]
+        mass, position, radius, velocity, types, softening = ([] for _ in range(6))
+        for ptype in PTYPES:
+            if ptype not in data:
+                continue
+            d = data[ptype]
+            grnr = d["GroupNr_bound"]
+            in_halo = np.ones(grnr.shape, dtype=bool) if self.inclusive else grnr == index
+            mass.append(d["Masses"][in_halo])
+            pos = d["Coordinates"][in_halo, :] - centre[None, :]
+            position.append(pos)
+            r = np.sqrt(pos[:, 0] ** 2 + pos[:, 1] ** 2 + pos[:, 2] ** 2)
+            radius.append(r)
+            velocity.append(d["Velocities"][in_halo, :])
+            types.append(ptype * np.ones(r.shape, dtype=np.int32))
+            softening.append(np.ones(r.shape, dtype=np.float64) * u.softening_comoving(ptype))
+        mass = np.concatenate(mass)
+        position = np.concatenate(position)
+        radius = np.concatenate(radius)
+        velocity = np.concatenate(velocity)
+        types_all = np.concatenate(types)
+        softening = np.concatenate(softening)
+        mask = radius <= aperture_radius
+        mass = mass[mask]
+        position = position[mask]
+        velocity = velocity[mask]
+        radius = radius[mask]
+        type_ = types_all[mask]
+        softening = softening[mask]
+
+        out = {}
+        N = {t: int(mask[types_all == t].sum()) for t in PTYPES}
+        out["Ngas"], out["Ndm"], out["Nstar"], out["Nbh"] = N[0], N[1], N[4], N[5]
+        Mtot = mass.sum()
+        out["Mtot"] = Mtot
+        M_t = {t: mass[type_ == t].sum() for t in PTYPES}
+        out["Mgas"], out["Mdm"], out["Mstar"], out["Mbh_dynamical"] = M_t[0], M_t[1], M_t[4], M_t[5]
+        if Mtot != 0:
+            frac = mass / Mtot
+            out["com"] = ((frac[:, None] * position).sum(axis=0) + centre) % u.boxsize
+            out["vcom"] = (frac[:, None] * velocity).sum(axis=0)
+            soft_r = np.maximum(softening, radius)
+            out["R_vmax_soft"], out["Vmax_soft"] = get_vmax(mass, soft_r, u.G_eff)
+        dm = type_ == 1
+        if M_t[1] != 0:
+            fdm = mass[dm] / M_t[1]
+            vcom_dm = (fdm[:, None] * velocity[dm]).sum(axis=0)
+            out["veldisp_matrix_dm"] = get_velocity_dispersion_matrix(fdm, velocity[dm], vcom_dm)[0]
+            out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
+        out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
+        return out
+
+
+# --------------------------------------------------------------------------
+# projected apertures (projected_aperture_properties.py)
+# --------------------------------------------------------------------------
+class ProjectedApertureProperties:
+    """projected_aperture_properties.py:98-142, :172-198, :254-378, :739-786, :946-957,
+    :1491-1577, :1798-2002 -- DMO/basic subset; bound particles only."""
+
+    property_list = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar",
+                     "Nbh", "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm"]  # fmt: skip
+
+    def __init__(self, units: Units, radius_kpc: float, all_radii_kpc=None,
+                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
+        self.units = units
+        self.aperture_physical_radius_kpc = radius_kpc
+        self.all_radii_kpc = list(all_radii_kpc) if all_radii_kpc is not None else [radius_kpc]
+        self.halo_filter = halo_filter
+        self.filters = filters
+        self.dmo = dmo
+        self.physical_radius_mpc = 0.001 * radius_kpc
+        self.mean_density_multiple = None
+        self.critical_density_multiple = None
+        aperture_name = f"{1000*radius_kpc:.0f}pc" if radius_kpc < 1 else f"{radius_kpc:.0f}kpc"
+        self.name = f"projected_aperture_{aperture_name}"
+        self.group_name = f"ProjectedAperture/{aperture_name}"
+
+    def calculate(self, input_halo, search_radius, data, halo_result):
+        u = self.units
+        do_calc = get_do_calculation(self.filters, halo_result["_counts"], self.dmo)
+        skip = False
+        copied = None
+        i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc)
+        if i_radius != 0 and ("BoundSubhalo/EncloseRadius" in halo_result):
+            r_enclose = float(halo_result["BoundSubhalo/EncloseRadius"].stored[0])
+            r_previous_kpc = self.all_radii_kpc[i_radius - 1]
+            if u.kpc_to_comoving(r_previous_kpc) > r_enclose:
+                skip = True
+                if do_calc[self.halo_filter]:
+                    prev = (f"{1000*r_previous_kpc:.0f}pc" if r_previous_kpc < 1
+                            else f"{r_previous_kpc:.0f}kpc")  # fmt: skip
+                    copied = f"ProjectedAperture/{prev}"
+        outs = {p: {} for p in ("projx", "projy", "projz")}
+        if do_calc[self.halo_filter] and not skip:
+            aperture_radius = u.kpc_to_comoving(self.aperture_physical_radius_kpc)
+            outs = self._calculate(input_halo, aperture_radius, data)
+        for proj in ("projx", "projy", "projz"):
+            g = f"{self.group_name}/{proj}"
+            for key in self.property_list:
+                if copied is not None:
+                    pv = halo_result[f"{copied}/{proj}/{key}"]
+                    halo_result[f"{g}/{key}"] = Value(pv.raw.copy(), pv.stored.copy())
+                else:
+                    _store(halo_result, g, key, outs[proj].get(key))
+
+    def _calculate(self, input_halo, aperture_radius, data):
+        u = self.units
+        centre = input_halo["cofp"]
+        index = input_halo["index"]
+        mass, position, velocity, types = ([] for _ in range(4))
+        rp = ([], [], [])
+        for ptype in PTYPES:
+            if ptype not in data:
+                continue
+            d = data[ptype]
+            in_halo = d["GroupNr_bound"] == index
+            mass.append(d["Masses"][in_halo])
+            pos = d["Coordinates"][in_halo, :] - centre[None, :]
+            position.append(pos)
+            rp[0].append(np.sqrt(pos[:, 1] ** 2 + pos[:, 2] ** 2))
+            rp[1].append(np.sqrt(pos[:, 0] ** 2 + pos[:, 2] ** 2))
+            rp[2].append(np.sqrt(pos[:, 0] ** 2 + pos[:, 1] ** 2))
+            velocity.append(d["Velocities"][in_halo, :])
+            types.append(ptype * np.ones(pos.shape[0], dtype=np.int32))
+        mass = np.concatenate(mass)
+        position = np.concatenate(position)
+        velocity = np.concatenate(velocity)
+        types = np.concatenate(types)
+        outs = {}
+        for iproj, proj in enumerate(("projx", "projy", "projz")):
+            projr = np.concatenate(rp[iproj])
+            pm = projr <= aperture_radius
+            m = mass[pm]
+            x = position[pm]
+            v = velocity[pm]
+            r = projr[pm]
+            t = types[pm]
+            out = {}
+            N = {tt: int((t == tt).sum()) for tt in PTYPES}
+            out["Ngas"], out["Ndm"], out["Nstar"], out["Nbh"] = N[0], N[1], N[4], N[5]
+            Mtot = m.sum()
+            out["Mtot"] = Mtot
+            M_t = {tt: m[t == tt].sum() for tt in PTYPES}
+            out["Mgas"], out["Mdm"], out["Mstar"], out["Mbh_dynamical"] = (
+                M_t[0], M_t[1], M_t[4], M_t[5])  # fmt: skip
+            if Mtot != 0:
+                frac = m / Mtot
+                out["com"] = ((frac[:, None] * x).sum(axis=0) + centre) % u.boxsize
+                out["vcom"] = (frac[:, None] * v).sum(axis=0)
+            dm = t == 1
+            if M_t[1] != 0:
+                fdm = m[dm] / M_t[1]
+                pv = v[dm, iproj]
+                vc = (fdm * pv).sum()
+                out["proj_veldisp_dm"] = np.sqrt((fdm * (pv - vc) ** 2).sum())
+            out["HalfMassRadiusDM"] = get_half_weight_radius(r[dm], m[dm], M_t[1])
+            outs[proj] = out
+        return outs
+
+
+# --------------------------------------------------------------------------
+# L2 scheduler (SOAP/core/halo_tasks.py)
+# --------------------------------------------------------------------------
+def target_density_of(halo_prop_list, units: Units) -> Optional[float]:
+    """halo_tasks.py:306-317; returned in comoving code density."""
+    target = None
+    for hp in halo_prop_list:
+        if hp.mean_density_multiple is not None:
+            d = hp.mean_density_multiple * units.mean_density
+            if target is None or d < target:
+                target = d
+        if hp.critical_density_multiple is not None:
+            d = hp.critical_density_multiple * units.critical_density
+            if target is None or d < target:
+                target = d
+    return None if target is None else units.density_to_comoving(target)
+
+
+def process_single_halo(mesh, data, halo_prop_list, units: Units, input_halo, target_density,
+                        stats=None):  # fmt: skip
+    """
+    halo_tasks.py:23-187.  data[ptype] = dict(Coordinates, Velocities, Masses,
+    GroupNr_bound, FOFGroupIDs).  Returns halo_result (dict) or None when a larger
+    region must be read (input_halo["search_radius"] is then updated, as in the
+    reference).  `stats` (optional dict) receives n_loop, n_sel and n_cand of the
+    final iteration (for the particle-aperture-evaluation metric).
+    """
+    boxsize = units.boxsize
+    halo_prop_done = np.zeros(len(halo_prop_list), dtype=bool)
+    halo_result = {}
+    current_radius = input_halo["search_radius"]
+    n_loop = 0
+    while True:
+        n_loop += 1
+        assert current_radius <= input_halo["read_radius"]
+        mass_total = 0.0
+        idx = {}
+        ncand = 0
+        for ptype in data:
+            pos = data[ptype]["Coordinates"]
+            idx[ptype], nc = mesh[ptype].query_radius_periodic(
+                input_halo["cofp"], current_radius, pos, boxsize, return_ncand=True
+            )
+            ncand += nc
+            if ptype in PTYPES_FOR_SO_MASSES:
+                mass_total += np.sum(data[ptype]["Masses"][idx[ptype]], dtype=float)
+        density = mass_total / (4.0 / 3.0 * np.pi * current_radius**3)
+        max_physical_radius_mpc = 0.0
+        if target_density is None or density <= target_density:
+            particle_data = {}
+            for ptype in data:
+                particle_data[ptype] = {}
+                for name in data[ptype]:
+                    particle_data[ptype][name] = data[ptype][name][idx[ptype], ...]
+            for ptype in particle_data:
+                pos = particle_data[ptype]["Coordinates"]
+                offset = input_halo["cofp"] - 0.5 * boxsize
+                pos[:, :] = ((pos - offset) % boxsize) + offset
+            for prop_nr, halo_prop in enumerate(halo_prop_list):
+                if halo_prop_done[prop_nr]:
+                    continue
+                try:
+                    halo_prop.calculate(input_halo, current_radius, particle_data, halo_result)
+                except SearchRadiusTooSmallError:
+                    max_physical_radius_mpc = max(
+                        max_physical_radius_mpc, halo_prop.physical_radius_mpc
+                    )
+                    break
+                else:
+                    halo_prop_done[prop_nr] = True
+            if np.all(halo_prop_done):
+                if stats is not None:
+                    stats["n_loop"] = n_loop
+                    stats["n_sel"] = int(sum(len(v) for v in idx.values()))
+                    stats["n_cand"] = int(ncand)
+                    stats["final_radius"] = float(current_radius)
+                break
+        search_radius = input_halo["search_radius"]
+        required_radius = units.mpc_to_comoving(max_physical_radius_mpc)
+        if required_radius > input_halo["read_radius"]:
+            input_halo["search_radius"] = max(search_radius, required_radius)
+            return None
+        elif current_radius >= input_halo["read_radius"]:
+            input_halo["search_radius"] = max(search_radius, current_radius)
+            return None
+        else:
+            current_radius = min(current_radius * SEARCH_RADIUS_FACTOR, input_halo["read_radius"])
+            current_radius = max(current_radius, required_radius)
+    return halo_result
+
+
+def process_halos(mesh, data, halo_prop_list, units: Units, halo_arrays, stats_list=None):
+    """
+    halo_tasks.py:276-430, single rank.  halo_arrays: dict of arrays (index, cofp,
+    search_radius, read_radius, is_central, nr_bound_part, done).  Halos are visited
+    in array order (the caller sorts by nr_bound_part descending, chunk_tasks.py:118).
+    Returns the list of (halo position in arrays, halo_result).
+    """
+    target_density = target_density_of(halo_prop_list, units)
+    results = []
+    nr_halos = len(halo_arrays["index"])
+    for i in range(nr_halos):
+        if halo_arrays["done"][i] != 0:
+            continue
+        input_halo = {name: halo_arrays[name][i, ...].copy() for name in halo_arrays}
+        stats = {} if stats_list is not None else None
+        halo_result = process_single_halo(
+            mesh, data, halo_prop_list, units, input_halo,
+            target_density if input_halo["is_central"] == 1 else None, stats,
+        )  # fmt: skip
+        if halo_result is not None:
+            halo_result.pop("_counts", None)
+            results.append((i, halo_result))
+            halo_arrays["done"][i] = 1
+            if stats_list is not None:
+                stats_list.append(stats)
+        else:
+            new_read_radius = max(
+                input_halo["read_radius"] * READ_RADIUS_FACTOR, input_halo["search_radius"]
+            )
+            halo_arrays["read_radius"][i] = new_read_radius
+            halo_arrays["search_radius"][i] = input_halo["search_radius"]
+    return results

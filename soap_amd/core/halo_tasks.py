@@ -1,0 +1,159 @@
+"""
+Chunk-level scheduler: the drop-in for `process_halos` of SOAP/core/halo_tasks.py:276-430.
+
+The reference pulls one halo at a time off an MPI RMA counter and runs
+process_single_halo() (halo_tasks.py:23-273) in Python; here the whole halo table of the
+chunk goes to the HIP engine in one call (the search-radius loop, the calculation list
+and the retry rules all run on the device, one workgroup per halo) and the result table
+is unpacked into the same `halo_result` dictionaries.
+"""
+
+from __future__ import annotations
+
+import time
+from typing import Dict, List
+
+import numpy as np
+
+from ..engine import (STATUS_NEED_LARGER_READ_RADIUS, STATUS_OK, Engine, SLOT_OF_PTYPE,
+                      mesh_resolution)  # fmt: skip
+from ..particle_selection.halo_properties import SearchRadiusTooSmallError  # noqa: F401
+
+# Factors of the reference (halo_tasks.py:14-20); applied on the device, quoted here for
+# the host-side bookkeeping and the documentation.
+SEARCH_RADIUS_FACTOR = 1.2
+READ_RADIUS_FACTOR = 1.5
+REPORT_RADIUS = 20.0
+
+_FATAL_TEXT = {
+    -1: "Found more particles than expected for halo {index}",  # subhalo_properties.py:2642-2646
+    -2: "Cannot find SO radius, but search radius is already larger than 20 Mpc! (halo {index})",
+    -3: "search sphere of halo {index} does not fit the engine's slab",
+    -4: "current_radius > read_radius for halo {index} (halo_tasks.py:78)",
+}
+
+_INPUT_HALO_COLUMNS = {
+    # halo_arrays name -> (dataset name, dtype, description, physical, a-exponent)
+    "cofp": ("InputHalos/HaloCentre", np.float64,
+             "Centre of the subhalo as given by the halo finder.", False, 1),
+    "index": ("InputHalos/HaloCatalogueIndex", np.int64,
+              "Index of this halo in the halo finder catalogue.", True, None),
+    "is_central": ("InputHalos/IsCentral", np.int64,
+                   "Whether the halo finder flagged the halo as central (1) or satellite (0).", True, None),
+    "nr_bound_part": ("InputHalos/NumberOfBoundParticles", np.int64,
+                      "Total number of particles bound to the subhalo.", True, None),
+}  # fmt: skip
+
+
+def target_density_of(halo_prop_list, cellgrid):
+    """Minimum density any calculation needs (halo_tasks.py:306-317), converted once to
+    mass / comoving length^3.  None if no calculation sets a density multiple."""
+    target = None
+    for halo_prop in halo_prop_list:
+        if halo_prop.mean_density_multiple is not None:
+            density = halo_prop.mean_density_multiple * cellgrid.mean_density
+            if target is None or density < target:
+                target = density
+        if halo_prop.critical_density_multiple is not None:
+            density = halo_prop.critical_density_multiple * cellgrid.critical_density
+            if target is None or density < target:
+                target = density
+    return None if target is None else cellgrid.density_to_comoving(target)
+
+
+def make_engine(cellgrid, device=0, **kw) -> Engine:
+    """Engine configured from the cell grid scalars (what HaloProperty.__init__ copies)."""
+    soft = cellgrid.softening_comoving()
+    return Engine(
+        boxsize=cellgrid.boxsize,
+        G_eff=cellgrid.G_eff,
+        softening=[soft] * 4,
+        nu_density=cellgrid.nu_density_comoving,
+        mpc20=cellgrid.mpc_to_comoving(20.0),
+        device=device,
+        **kw,
+    )
+
+
+def stage_chunk(engine: Engine, data: Dict, resolution=None):
+    """
+    Put the chunk's particle arrays in HBM and build one cell-list mesh per particle type:
+    the counterpart of share_array + SharedMesh(comm, pos, resolution) in
+    ChunkTask.__call__ (SOAP/core/chunk_tasks.py:165-170, :293-304).
+    data[ptype] = {"Coordinates","Velocities","Masses"|"DynamicalMasses","GroupNr_bound",
+    "FOFGroupIDs"}; ptype is 0/1/4/5 or "PartType0"...; arrays are NumPy or torch-CUDA.
+    """
+    for ptype, d in data.items():
+        pt = int(str(ptype)[-1]) if not isinstance(ptype, int) else ptype
+        if pt not in SLOT_OF_PTYPE:
+            continue  # neutrinos (PartType6) are not part of the engine yet
+        n = int(d["Coordinates"].shape[0])
+        mass = d["DynamicalMasses"] if (pt == 5 and "DynamicalMasses" in d) else d["Masses"]
+        res = mesh_resolution(n) if resolution is None else resolution
+        engine.stage_particles(SLOT_OF_PTYPE[pt], d["Coordinates"], d["Velocities"], mass,
+                               d["GroupNr_bound"], d["FOFGroupIDs"], res)  # fmt: skip
+
+
+def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, results,
+                  unpack: bool = True):  # fmt: skip
+    """
+    Compute every calculation of `halo_prop_list` for every halo of `halo_arrays` with
+    done == 0.  halo_arrays: dict of NumPy arrays index, cofp, search_radius, read_radius,
+    is_central, nr_bound_part, done (already in processing order).  Finished halos get
+    done=1 and one `halo_result` dict appended to `results` (anything with .append);
+    halos that need a larger region get their read_radius/search_radius updated exactly as
+    the reference does (halo_tasks.py:393-402) and stay at done=0.
+
+    Returns (total_time, task_time, nr_halos_left, nr_done, raw) where raw holds the
+    engine's table/status/stats for callers that do not want per-halo dictionaries.
+    """
+    t0_all = time.time()
+    todo = np.flatnonzero(np.asarray(halo_arrays["done"]) == 0)
+    calcs = [hp.calc_desc(halo_prop_list, i) for i, hp in enumerate(halo_prop_list)]
+    target_density = target_density_of(halo_prop_list, cellgrid)
+    engine.stage_halos(
+        halo_arrays["cofp"][todo], halo_arrays["search_radius"][todo],
+        halo_arrays["read_radius"][todo], halo_arrays["index"][todo],
+        halo_arrays["is_central"][todo], halo_arrays["nr_bound_part"][todo],
+    )  # fmt: skip
+    t0_task = time.time()
+    engine.run(calcs, target_density)
+    out = engine.fetch()
+    task_time = time.time() - t0_task
+
+    status = out["status"]
+    fatal = np.flatnonzero(status < 0)
+    if fatal.size:
+        i = int(fatal[0])
+        index = int(halo_arrays["index"][todo[i]])
+        # same convention as the reference: report the halo, then abort the chunk
+        print(f"Object with HaloCatalogueIndex={index} encountered an error")
+        raise RuntimeError(_FATAL_TEXT[int(status[i])].format(index=index))
+
+    ok = status == STATUS_OK
+    again = status == STATUS_NEED_LARGER_READ_RADIUS
+    halo_arrays["done"][todo[ok]] = 1
+    halo_arrays["read_radius"][todo[again]] = out["read_radius"][again]
+    halo_arrays["search_radius"][todo[again]] = out["search_radius"][again]
+
+    if unpack:
+        coloff = np.concatenate([[0], np.cumsum([engine._lib.soap_engine_calc_columns(c.kind) for c in calcs])])
+        table = out["table"]
+        for j in np.flatnonzero(ok):
+            row = table[j]
+            halo_result = {}
+            do_calc = None
+            for ci, hp in enumerate(halo_prop_list):
+                hp.unpack(row[coloff[ci] : coloff[ci + 1]], halo_result, do_calc)
+                if ci == 0 and getattr(hp, "category_filter", None) is not None:
+                    # property-level filters use the bound subhalo's particle counts
+                    # (subhalo_properties.py:2618-2626)
+                    do_calc = hp.category_filter.get_do_calculation(halo_result)
+            i = todo[j]
+            for name, (dset, dtype, desc, phys, aexp) in _INPUT_HALO_COLUMNS.items():
+                halo_result[dset] = (np.asarray(halo_arrays[name][i]).astype(dtype), desc, phys, aexp)
+            results.append(halo_result)
+
+    nr_left = int(np.sum(np.asarray(halo_arrays["done"]) == 0))
+    raw = dict(out, rows=todo)
+    return time.time() - t0_all, task_time, nr_left, int(ok.sum()), raw

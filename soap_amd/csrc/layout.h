@@ -1,0 +1,45 @@
+// Column layout of the fp64 result table, per calculation kind.
+// Mirrored by soap_amd/layout.py (tests/test_abi.py checks the two agree).
+#pragma once
+
+// ---- SOAP_CALC_SUBHALO (BoundSubhalo) -----------------------------------------
+enum {
+    SH_Mtot = 0, SH_Mgas, SH_Mdm, SH_Mstar, SH_Mbh,
+    SH_Ngas, SH_Ndm, SH_Nstar, SH_Nbh,
+    SH_com = 9, SH_vcom = 12, SH_Ldm = 15,
+    SH_Vmax_unsoft = 18, SH_Vmax_soft, SH_R_vmax_unsoft, SH_spin,
+    SH_HMR_tot = 22, SH_HMR_dm,
+    SH_veldisp_dm = 24,
+    SH_EncloseRadius = 30,
+    SH_NCOLS = 31
+};
+// ---- SOAP_CALC_SO_* -------------------------------------------------------------
+enum {
+    SOC_r = 0, SOC_Mtot,
+    SOC_Ngas, SOC_Ndm, SOC_Nstar, SOC_Nbh,
+    SOC_com = 6, SOC_vcom = 9,
+    SOC_Vmax_soft = 12, SOC_R_vmax_soft,
+    SOC_Mfrac_sat = 14, SOC_Mfrac_ext,
+    SOC_Mgas = 16, SOC_Mdm,
+    SOC_Ldm = 18,
+    SOC_Mstar = 21, SOC_Mbh,
+    SOC_spin = 23, SOC_conc_unsoft, SOC_conc_soft,
+    SOC_NCOLS = 26
+};
+// ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
+enum {
+    AP_Mtot = 0, AP_Mgas, AP_Mdm, AP_Mstar, AP_Mbh,
+    AP_Ngas, AP_Ndm, AP_Nstar, AP_Nbh,
+    AP_com = 9, AP_vcom = 12, AP_Ldm = 15,
+    AP_veldisp_dm = 18,
+    AP_HMR_dm = 24, AP_Vmax_soft, AP_R_vmax_soft,
+    AP_NCOLS = 27
+};
+// ---- SOAP_CALC_PROJECTED: 3 blocks (projx, projy, projz) of PJ_NCOLS ---------------
+enum {
+    PJ_Mtot = 0, PJ_Mgas, PJ_Mdm, PJ_Mstar, PJ_Mbh,
+    PJ_Ngas, PJ_Ndm, PJ_Nstar, PJ_Nbh,
+    PJ_com = 9, PJ_vcom = 12,
+    PJ_HMR_dm = 15, PJ_veldisp_dm,
+    PJ_NCOLS = 17
+};

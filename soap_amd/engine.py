@@ -1,0 +1,181 @@
+"""
+Thin object wrapper over the C ABI (include/soap_engine.h).  Accepts NumPy arrays (host
+pointers) or torch CUDA tensors (device pointers; torch is only plumbing for HBM
+residency, it never computes anything on this path).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CalcDesc, EngineConfig
+
+STATUS_OK = 0
+STATUS_NEED_LARGER_READ_RADIUS = 1
+STATUS_FATAL_TOO_MANY_BOUND = -1
+STATUS_FATAL_SO_BEYOND_20MPC = -2
+STATUS_FATAL_SLAB_OVERFLOW = -3
+STATUS_FATAL_RADIUS_ASSERT = -4
+
+# type slot <-> SWIFT particle type
+PTYPE_OF_SLOT = (0, 1, 4, 5)
+SLOT_OF_PTYPE = {0: 0, 1: 1, 4: 2, 5: 3}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _ptr(x, dtype, shape_tail=()):
+    """(pointer, on_device, keepalive) of a contiguous array of `dtype`."""
+    if _is_torch(x):
+        import torch
+
+        tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dtype]
+        if x.dtype != tdt:
+            raise TypeError(f"expected torch dtype {tdt}, got {x.dtype}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return C.c_void_p(x.data_ptr()), bool(x.is_cuda), x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return C.c_void_p(a.ctypes.data), False, a
+
+
+def mesh_resolution(nr_parts: int) -> int:
+    """Cells per dimension for ~1000 particles per cell, at most 256
+    (SOAP/core/chunk_tasks.py:299-302)."""
+    resolution = int((nr_parts / 1000) ** (1.0 / 3.0))
+    return min(max(resolution, 1), 256)
+
+
+class Engine:
+    """One GPU's halo-property engine (one handle = one chunk at a time)."""
+
+    def __init__(self, boxsize, G_eff, softening, nu_density=0.0, mpc20=float("inf"),
+                 device=0, n_workgroups=0, slab_capacity=0):  # fmt: skip
+        self._lib = _lib.load()
+        cfg = EngineConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.device = int(device)
+        cfg.boxsize = float(boxsize)
+        cfg.G_eff = float(G_eff)
+        cfg.nu_density = float(nu_density)
+        cfg.mpc20 = float(mpc20)
+        for i in range(_lib.NTYPES):
+            cfg.softening[i] = float(softening[i])
+        cfg.n_workgroups = int(n_workgroups)
+        cfg.slab_capacity = int(slab_capacity)
+        self._h = C.c_void_p()
+        self._check(self._lib.soap_engine_create(C.byref(cfg), C.byref(self._h)))
+        self.n_halo = 0
+        self.calcs = []
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"soap_engine error {rc}: {_lib.last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.soap_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging ---------------------------------------------------------------------
+    def stage_particles(self, type_slot, pos, vel, mass, grnr, fof, resolution=None):
+        n = int(pos.shape[0])
+        if resolution is None:
+            resolution = mesh_resolution(n)
+        p_pos, dev, k1 = _ptr(pos, np.float64)
+        p_vel, dev2, k2 = _ptr(vel, np.float64)
+        p_m, dev3, k3 = _ptr(mass, np.float64)
+        if _is_torch(grnr):
+            import torch
+
+            gb = 8 if grnr.dtype == torch.int64 else 4
+        else:
+            grnr = np.asarray(grnr)
+            gb = 8 if grnr.dtype == np.int64 else 4
+        p_g, dev4, k4 = _ptr(grnr, np.int64 if gb == 8 else np.int32)
+        p_f, dev5, k5 = _ptr(fof, np.int64)
+        if len({dev, dev2, dev3, dev4, dev5}) != 1:
+            raise ValueError("all particle arrays must live on the same side (host or device)")
+        if tuple(pos.shape) != (n, 3) or tuple(vel.shape) != (n, 3):
+            raise ValueError("Coordinates/Velocities must have shape (n, 3)")
+        self._check(
+            self._lib.soap_engine_stage_particles(
+                self._h, int(type_slot), n, p_pos, p_vel, p_m, p_g, gb, p_f, int(resolution),
+                1 if dev else 0,
+            )  # fmt: skip
+        )
+
+    def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part):
+        n = int(np.asarray(index).shape[0])
+        a = [
+            np.ascontiguousarray(cofp, dtype=np.float64).reshape(n, 3),
+            np.ascontiguousarray(search_radius, dtype=np.float64),
+            np.ascontiguousarray(read_radius, dtype=np.float64),
+            np.ascontiguousarray(index, dtype=np.int64),
+            np.ascontiguousarray(is_central, dtype=np.int32),
+            np.ascontiguousarray(nr_bound_part, dtype=np.int64),
+        ]
+        self._check(
+            self._lib.soap_engine_stage_halos(self._h, n, *[C.c_void_p(x.ctypes.data) for x in a])
+        )
+        self.n_halo = n
+
+    # -- run / fetch -------------------------------------------------------------------
+    def run(self, calcs: Sequence[CalcDesc], target_density):
+        arr = (CalcDesc * len(calcs))(*calcs)
+        td = -1.0 if target_density is None else float(target_density)
+        self._check(self._lib.soap_engine_run(self._h, arr, len(calcs), td))
+        self.calcs = list(calcs)
+
+    @property
+    def row_columns(self):
+        return int(self._lib.soap_engine_row_columns(self._h))
+
+    def fetch(self):
+        n, nc = self.n_halo, self.row_columns
+        table = np.zeros((n, nc), dtype=np.float64)
+        status = np.zeros(n, dtype=np.int32)
+        search = np.zeros(n, dtype=np.float64)
+        read = np.zeros(n, dtype=np.float64)
+        stats = np.zeros((n, 4), dtype=np.int64)
+        if n > 0:
+            self._check(
+                self._lib.soap_engine_fetch(
+                    self._h, *[C.c_void_p(x.ctypes.data) for x in (table, status, search, read, stats)]
+                )
+            )
+        return dict(table=table, status=status, search_radius=search, read_radius=read, stats=stats)
+
+    def table_device_ptr(self):
+        return self._lib.soap_engine_table_device(self._h)
+
+    def membership(self, row, type_slot, radius, strict, bound_only=False, cap=1 << 22):
+        out = np.zeros(cap, dtype=np.int64)
+        n = self._lib.soap_engine_membership(
+            self._h, int(row), int(type_slot), float(radius), 1 if strict else 0,
+            1 if bound_only else 0, C.c_void_p(out.ctypes.data), cap,
+        )  # fmt: skip
+        if n < 0:
+            raise EngineError(f"membership failed: {_lib.last_error()}")
+        if n > cap:
+            return self.membership(row, type_slot, radius, strict, bound_only, cap=int(n))
+        return out[:n].copy()
+
+    def kernel_ms(self, name: str) -> float:
+        return float(self._lib.soap_engine_kernel_ms(self._h, name.encode()))

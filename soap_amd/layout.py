@@ -1,0 +1,65 @@
+"""
+Column layout of the engine's fp64 result table; mirrors soap_amd/csrc/layout.h
+(tests/test_abi.py checks both against soap_engine_calc_columns()).
+
+Keys are the reference's internal property keys (SOAP/property_table.py
+`full_property_list` keys); values are (first column, number of columns).
+"""
+
+CALC_SUBHALO = 0
+CALC_SO_DENSITY = 1
+CALC_SO_PHYSICAL = 2
+CALC_SO_MULTIPLE = 3
+CALC_APERTURE_INCL = 4
+CALC_APERTURE_EXCL = 5
+CALC_PROJECTED = 6
+
+SUBHALO_COLS = {
+    "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
+    "Ngas": (5, 1), "Ndm": (6, 1), "Nstar": (7, 1), "Nbh": (8, 1),
+    "com": (9, 3), "vcom": (12, 3), "Ldm": (15, 3),
+    "Vmax_unsoft": (18, 1), "Vmax_soft": (19, 1), "R_vmax_unsoft": (20, 1), "spin_parameter": (21, 1),
+    "HalfMassRadiusTot": (22, 1), "HalfMassRadiusDM": (23, 1),
+    "veldisp_matrix_dm": (24, 6), "EncloseRadius": (30, 1),
+}  # fmt: skip
+SO_COLS = {
+    "r": (0, 1), "Mtot": (1, 1), "Ngas": (2, 1), "Ndm": (3, 1), "Nstar": (4, 1), "Nbh": (5, 1),
+    "com": (6, 3), "vcom": (9, 3), "Vmax_soft": (12, 1), "R_vmax_soft": (13, 1),
+    "Mfrac_satellites": (14, 1), "Mfrac_external": (15, 1), "Mgas": (16, 1), "Mdm": (17, 1),
+    "Ldm": (18, 3), "Mstar": (21, 1), "Mbh_dynamical": (22, 1), "spin_parameter": (23, 1),
+    "concentration_unsoft": (24, 1), "concentration_soft": (25, 1),
+}  # fmt: skip
+APERTURE_COLS = {
+    "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
+    "Ngas": (5, 1), "Ndm": (6, 1), "Nstar": (7, 1), "Nbh": (8, 1),
+    "com": (9, 3), "vcom": (12, 3), "Ldm": (15, 3), "veldisp_matrix_dm": (18, 6),
+    "HalfMassRadiusDM": (24, 1), "Vmax_soft": (25, 1), "R_vmax_soft": (26, 1),
+}  # fmt: skip
+PROJECTED_COLS = {
+    "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
+    "Ngas": (5, 1), "Ndm": (6, 1), "Nstar": (7, 1), "Nbh": (8, 1),
+    "com": (9, 3), "vcom": (12, 3), "HalfMassRadiusDM": (15, 1), "proj_veldisp_dm": (16, 1),
+}  # fmt: skip
+PROJECTED_NCOLS = 17
+
+NCOLS = {
+    CALC_SUBHALO: 31,
+    CALC_SO_DENSITY: 26,
+    CALC_SO_PHYSICAL: 26,
+    CALC_SO_MULTIPLE: 26,
+    CALC_APERTURE_INCL: 27,
+    CALC_APERTURE_EXCL: 27,
+    CALC_PROJECTED: 3 * PROJECTED_NCOLS,
+}
+
+
+def columns_of(kind):
+    if kind == CALC_SUBHALO:
+        return SUBHALO_COLS
+    if kind in (CALC_SO_DENSITY, CALC_SO_PHYSICAL, CALC_SO_MULTIPLE):
+        return SO_COLS
+    if kind in (CALC_APERTURE_INCL, CALC_APERTURE_EXCL):
+        return APERTURE_COLS
+    if kind == CALC_PROJECTED:
+        return PROJECTED_COLS
+    raise KeyError(kind)

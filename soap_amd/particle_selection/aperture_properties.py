@@ -1,0 +1,91 @@
+"""
+Fixed spherical apertures, inclusive (all particles) and exclusive (bound only):
+SOAP/particle_selection/aperture_properties.py:3702-4398.
+"""
+
+from __future__ import annotations
+
+from .. import layout
+from .halo_properties import HaloProperty
+from .subhalo_properties import _property_filters
+
+
+def _aperture_name(radius_kpc):
+    if radius_kpc < 1:
+        return f"{1000*radius_kpc:.0f}pc"
+    return f"{radius_kpc:.0f}kpc"
+
+
+class ApertureProperties(HaloProperty):
+    base_halo_type = "ApertureProperties"
+    property_names = [
+        "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
+        "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
+    ]  # fmt: skip
+
+    def __init__(self, cellgrid, parameters, aperture_physical_radius_kpc, aperture_property,
+                 recently_heated_gas_filter, stellar_age_calculator, cold_dense_gas_filter,
+                 category_filter, halo_filter, inclusive, all_radii_kpc):  # fmt: skip
+        super().__init__(cellgrid)
+        if aperture_physical_radius_kpc is None or aperture_property is not None:
+            raise NotImplementedError(
+                "apertures defined by another property (aperture_properties.py:3975-3986) are not built yet"
+            )
+        assert aperture_physical_radius_kpc >= 0.001
+        self.category_filter = category_filter
+        self.halo_filter = halo_filter
+        self.property_filters = _property_filters(parameters, self)
+        self.all_radii_kpc = list(all_radii_kpc)
+        self.aperture_physical_radius_kpc = aperture_physical_radius_kpc
+        self.aperture_property = None
+        self.inclusive = inclusive
+        self.physical_radius_mpc = 0.001 * aperture_physical_radius_kpc
+        aperture_name = _aperture_name(aperture_physical_radius_kpc)
+        if inclusive:
+            self.name = f"inclusive_sphere_{aperture_name}"
+            self.group_name = f"InclusiveSphere/{aperture_name}"
+            self.kind = layout.CALC_APERTURE_INCL
+        else:
+            self.name = f"exclusive_sphere_{aperture_name}"
+            self.group_name = f"ExclusiveSphere/{aperture_name}"
+            self.kind = layout.CALC_APERTURE_EXCL
+        self.mask_metadata = (
+            category_filter.get_filter_metadata(halo_filter) if category_filter else {"Masked": False}
+        )
+
+    def calc_desc(self, halo_prop_list, position):
+        d = self._base_desc()
+        d.radius = self.cellgrid.kpc_to_comoving(self.aperture_physical_radius_kpc)
+        # skip/copy rule (aperture_properties.py:4082-4123)
+        i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc)
+        if i_radius != 0:
+            r_prev = self.all_radii_kpc[i_radius - 1]
+            prefix = "InclusiveSphere" if self.inclusive else "ExclusiveSphere"
+            prev_group = f"{prefix}/{_aperture_name(r_prev)}"
+            for i, hp in enumerate(halo_prop_list[:position]):
+                if getattr(hp, "group_name", None) == prev_group:
+                    d.parent = i
+            if d.parent < 0:
+                raise RuntimeError(f"{prev_group} must be computed before {self.group_name}")
+            d.prev_radius = self.cellgrid.kpc_to_comoving(r_prev)
+        return d
+
+
+class ExclusiveSphereProperties(ApertureProperties):
+    def __init__(self, cellgrid, parameters, physical_radius_kpc, aperture_property,
+                 recently_heated_gas_filter, stellar_age_calculator, cold_dense_gas_filter,
+                 category_filter, halo_filter, all_radii_kpc):  # fmt: skip
+        super().__init__(cellgrid, parameters, physical_radius_kpc, aperture_property,
+                         recently_heated_gas_filter, stellar_age_calculator,
+                         cold_dense_gas_filter, category_filter, halo_filter, False,
+                         all_radii_kpc)  # fmt: skip
+
+
+class InclusiveSphereProperties(ApertureProperties):
+    def __init__(self, cellgrid, parameters, physical_radius_kpc, aperture_property,
+                 recently_heated_gas_filter, stellar_age_calculator, cold_dense_gas_filter,
+                 category_filter, halo_filter, all_radii_kpc):  # fmt: skip
+        super().__init__(cellgrid, parameters, physical_radius_kpc, aperture_property,
+                         recently_heated_gas_filter, stellar_age_calculator,
+                         cold_dense_gas_filter, category_filter, halo_filter, True,
+                         all_radii_kpc)  # fmt: skip

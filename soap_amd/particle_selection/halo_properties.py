@@ -1,0 +1,100 @@
+"""
+Base class of every halo calculation and the error that asks the scheduler for a
+larger search radius.  Mirrors SOAP/particle_selection/halo_properties.py:4-35.
+
+A HaloProperty here does not compute anything in Python: it describes one entry of
+`halo_prop_list` to the HIP engine (`calc_desc`) and knows how to turn its block of the
+engine's result table back into the reference's `halo_result` entries (`unpack`).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+from .. import layout
+from .._lib import CalcDesc
+from ..property_table import full_property_list, stored_value
+
+
+class SearchRadiusTooSmallError(Exception):
+    pass
+
+
+class HaloProperty:
+    # subclasses fill these in, with the same meaning as in the reference
+    base_halo_type = "HaloProperty"
+    name = ""
+    group_name = ""
+    halo_filter = "basic"
+    kind = -1  # engine calculation kind
+    property_names: List[str] = []  # internal keys, in output order
+
+    def __init__(self, cellgrid):
+        # fields copied from the cell grid (halo_properties.py:12-35)
+        self.cellgrid = cellgrid
+        self.critical_density = cellgrid.critical_density
+        self.mean_density = cellgrid.mean_density
+        self.a = cellgrid.a
+        self.z = 1.0 / cellgrid.a - 1.0
+        self.boxsize = cellgrid.boxsize
+        soft = cellgrid.softening
+        self.softening_of_parttype = {f"PartType{t}": soft for t in (0, 1, 4, 5, 6)}
+        self.mean_density_multiple = None
+        self.critical_density_multiple = None
+        self.physical_radius_mpc = 0.0
+        self.category_filter = None
+        self.property_filters: Dict[str, str] = {}
+
+    # ---- engine description --------------------------------------------------------
+    def calc_desc(self, halo_prop_list, position) -> CalcDesc:
+        raise NotImplementedError
+
+    def _base_desc(self) -> CalcDesc:
+        d = CalcDesc()
+        d.kind = self.kind
+        d.parent = -1
+        d.reference_density = 0.0
+        d.radius = 0.0
+        d.physical_radius_mpc = self.cellgrid.mpc_to_comoving(self.physical_radius_mpc)
+        d.prev_radius = 0.0
+        d.virial_definition = 0
+        limit, mask = (0, 0)
+        if self.category_filter is not None:
+            limit, mask = self.category_filter.engine_filter(self.halo_filter)
+        d.filter_limit = limit
+        d.filter_types = mask
+        return d
+
+    # ---- properties enabled for this run --------------------------------------------
+    def enabled_properties(self):
+        dmo = bool(self.category_filter is not None and self.category_filter.dmo)
+        out = []
+        for key in self.property_names:
+            prop = full_property_list[key]
+            if not self.property_filters.get(prop.name, "basic"):
+                continue
+            if dmo and not prop.dmo_property:
+                continue
+            out.append(key)
+        return out
+
+    # ---- result table -> halo_result --------------------------------------------------
+    def unpack(self, block: np.ndarray, halo_result: Dict, do_calculation=None):
+        """block: this calculation's columns of one halo row (fp64 raw values)."""
+        cols = layout.columns_of(self.kind)
+        for key in self.enabled_properties():
+            prop = full_property_list[key]
+            c0, nc = cols[key]
+            raw = block[c0 : c0 + nc].copy()
+            filt = self.property_filters.get(prop.name, "basic")
+            if do_calculation is not None and not do_calculation.get(filt, True):
+                raw[:] = 0.0
+            halo_result[f"{self.group_name}/{prop.name}"] = (
+                stored_value(key, raw, self.a),
+                prop.description,
+                prop.output_physical,
+                prop.a_scale_exponent,
+                raw,
+            )

@@ -1,0 +1,80 @@
+"""
+Output schema of the in-scope halo properties: our own restatement of the rows of
+SOAP/property_table.py `PropertyTable.full_property_list` that the hot path produces
+(SURVEY.md section 8(a) row a22).  Key = the reference's internal property key.
+
+Fields: output name, number of components, stored dtype, unit string, whether the
+stored value is physical (False = comoving, multiply the unit by a**a_exponent),
+a-scale exponent for comoving quantities, and whether a DMO run emits it.
+`a_power` is the power of the expansion factor that converts the engine's raw value
+(comoving lengths, code velocities/masses) into the stored unit.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class Property:
+    name: str
+    shape: int
+    dtype: type
+    unit: str
+    output_physical: bool
+    a_scale_exponent: int | None
+    dmo_property: bool
+    a_power: int = 0  # stored = raw * a**a_power
+    description: str = ""
+
+
+_M = "snap_mass"
+_Lc = "snap_length"
+_V = "snap_length/snap_time"
+_L = "snap_mass*snap_length**2/snap_time"
+_V2 = "snap_length**2/snap_time**2"
+
+full_property_list = {
+    # key: Property(name, shape, dtype, unit, physical, a_exp, dmo, a_power, description)
+    "r": Property("SORadius", 1, np.float32, _Lc, False, 1, True, 0, "Radius of the sphere {label}."),
+    "Mtot": Property("TotalMass", 1, np.float32, _M, True, None, True, 0, "Total mass."),
+    "Mgas": Property("GasMass", 1, np.float32, _M, True, None, False, 0, "Mass in gas particles."),
+    "Mdm": Property("DarkMatterMass", 1, np.float32, _M, True, None, True, 0, "Mass in dark matter particles."),
+    "Mstar": Property("StellarMass", 1, np.float32, _M, True, None, False, 0, "Mass in star particles."),
+    "Mbh_dynamical": Property("BlackHolesDynamicalMass", 1, np.float32, _M, True, None, False, 0, "Dynamical mass in black holes."),
+    "Ngas": Property("NumberOfGasParticles", 1, np.uint32, "dimensionless", True, None, False, 0, "Number of gas particles."),
+    "Ndm": Property("NumberOfDarkMatterParticles", 1, np.uint32, "dimensionless", True, None, True, 0, "Number of dark matter particles."),
+    "Nstar": Property("NumberOfStarParticles", 1, np.uint32, "dimensionless", True, None, False, 0, "Number of star particles."),
+    "Nbh": Property("NumberOfBlackHoleParticles", 1, np.uint32, "dimensionless", True, None, False, 0, "Number of black hole particles."),
+    "com": Property("CentreOfMass", 3, np.float64, _Lc, False, 1, True, 0, "Centre of mass."),
+    "vcom": Property("CentreOfMassVelocity", 3, np.float32, _V, True, None, True, 0, "Centre of mass velocity."),
+    "Ldm": Property("AngularMomentumDarkMatter", 3, np.float32, _L, True, None, True, 1, "Angular momentum of the dark matter about the dark matter centre of mass velocity."),
+    "veldisp_matrix_dm": Property("DarkMatterVelocityDispersionMatrix", 6, np.float32, _V2, True, None, True, 0, "Mass-weighted velocity dispersion of the dark matter (XX YY ZZ XY XZ YZ)."),
+    "proj_veldisp_dm": Property("DarkMatterProjectedVelocityDispersion", 1, np.float32, _V, True, None, True, 0, "Dark matter velocity dispersion along the projection axis."),
+    "HalfMassRadiusDM": Property("HalfMassRadiusDarkMatter", 1, np.float32, _Lc, False, 1, True, 0, "Dark matter half mass radius."),
+    "HalfMassRadiusTot": Property("HalfMassRadiusTotal", 1, np.float32, _Lc, False, 1, True, 0, "Total half mass radius."),
+    "EncloseRadius": Property("EncloseRadius", 1, np.float32, _Lc, False, 1, True, 0, "Radius of the outermost bound particle."),
+    "Vmax_soft": Property("MaximumCircularVelocity", 1, np.float32, _V, True, None, True, 0, "Maximum circular velocity, radii floored at the softening length."),
+    "R_vmax_soft": Property("MaximumCircularVelocityRadius", 1, np.float32, _Lc, False, 1, True, 0, "Radius of the maximum circular velocity (softened radii)."),
+    "Vmax_unsoft": Property("MaximumCircularVelocityUnsoftened", 1, np.float32, _V, True, None, True, 0, "Maximum circular velocity, raw radii."),
+    "R_vmax_unsoft": Property("MaximumCircularVelocityRadiusUnsoftened", 1, np.float32, _Lc, False, 1, True, 0, "Radius of the maximum circular velocity (raw radii)."),
+    "spin_parameter": Property("SpinParameter", 1, np.float32, "dimensionless", True, None, True, 0, "Bullock et al. (2001) spin parameter."),
+    "concentration_soft": Property("Concentration", 1, np.float32, "dimensionless", True, None, True, 0, "NFW concentration from the first radial moment (softened radii)."),
+    "concentration_unsoft": Property("ConcentrationUnsoftened", 1, np.float32, "dimensionless", True, None, True, 0, "NFW concentration from the first radial moment (raw radii)."),
+    "Mfrac_satellites": Property("MassFractionSatellites", 1, np.float32, "dimensionless", True, None, True, 0, "Mass fraction bound to satellites in the same FOF group."),
+    "Mfrac_external": Property("MassFractionExternal", 1, np.float32, "dimensionless", True, None, True, 0, "Mass fraction bound to subhalos outside this FOF group."),
+}  # fmt: skip
+
+
+def stored_value(key, raw, a):
+    """The value the reference would store: zero-initialised table-dtype array += value in
+    the table unit (SO_properties.py:3600-3620, :3682-3699), i.e. one cast."""
+    prop = full_property_list[key]
+    raw = np.atleast_1d(np.asarray(raw, dtype=np.float64))
+    if np.issubdtype(prop.dtype, np.integer):
+        return raw.astype(prop.dtype)
+    out = np.zeros(raw.shape, dtype=prop.dtype)
+    out += raw * (a**prop.a_power) if prop.a_power else raw
+    return out
