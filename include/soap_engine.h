@@ -48,6 +48,10 @@ typedef struct soap_engine_config {
     double G_eff;           /* Newton G / a : v^2 = G_eff * M / r_comoving */
     double nu_density;      /* mean neutrino density, mass / comoving length^3 */
     double mpc20;           /* 20 Mpc in comoving code length (SO_properties.py:150) */
+    double a;               /* expansion factor */
+    double mpc;             /* one PHYSICAL Mpc in physical code length.  Only used to mirror the
+                               reference's round trip of a radius-multiple SO's required radius
+                               through physical Mpc (SO_properties.py:3917, halo_tasks.py:168) */
     double softening[SOAP_NTYPES]; /* comoving code length per type slot */
     int32_t n_workgroups;   /* 0 = library default (persistent grid size) */
     int32_t slab_capacity;  /* 0 = default; max particles in one halo's search sphere */

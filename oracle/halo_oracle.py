@@ -811,8 +811,10 @@ class RadiusMultipleSOProperties(SOProperties):
         # :3917  physical_radius_mpc = multiple * R.to("Mpc").value  (float64 arithmetic)
         self._radius_comoving = self.multiple * float(r32)
         self.physical_radius_mpc = self._radius_comoving * self.units.a / (1000.0 * self.units.kpc)
-        # :3920  float32 array * python float stays float32 (NumPy>=2 promotion)
-        if np.float32(self.multiple) * r32 > search_radius:
+        # :3920  `multiple * halo_result[key][0]`: python float * 0-d float32 array stays
+        # float32 (NumPy>=2 promotion); it is then compared with the float64 search radius
+        # (both 0-d arrays in the reference, so the comparison itself is in float64)
+        if float(np.float32(self.multiple) * r32) > float(search_radius):
             raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
         super().calculate(input_halo, search_radius, data, halo_result)
 

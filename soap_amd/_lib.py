@@ -25,6 +25,8 @@ class EngineConfig(C.Structure):
         ("G_eff", C.c_double),
         ("nu_density", C.c_double),
         ("mpc20", C.c_double),
+        ("a", C.c_double),
+        ("mpc", C.c_double),
         ("softening", C.c_double * NTYPES),
         ("n_workgroups", C.c_int32),
         ("slab_capacity", C.c_int32),

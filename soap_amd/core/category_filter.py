@@ -56,7 +56,8 @@ class CategoryFilter:
                         v += pre[prop]
                     else:
                         val = halo_result[prop][0]
-                        v += int(getattr(val, "value", val))
+                        val = getattr(val, "value", val)
+                        v += int(val.reshape(-1)[0]) if hasattr(val, "reshape") else int(val)
                 do_calculation[name] = v >= info["limit"]
             else:
                 raise NotImplementedError(f"Invalid combine_properties function for filter {name}")

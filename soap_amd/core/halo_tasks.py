@@ -70,6 +70,8 @@ def make_engine(cellgrid, device=0, **kw) -> Engine:
         softening=[soft] * 4,
         nu_density=cellgrid.nu_density_comoving,
         mpc20=cellgrid.mpc_to_comoving(20.0),
+        a=cellgrid.a,
+        mpc=1000.0 * cellgrid.kpc,
         device=device,
         **kw,
     )

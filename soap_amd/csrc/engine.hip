@@ -98,7 +98,7 @@ struct RunParams {
     TypeDev t[SOAP_NTYPES];
     SlabDev slab;
     HaloDev halo;
-    double boxsize, G_eff, nu_density, mpc20, target_density;
+    double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -809,7 +809,9 @@ __device__ __noinline__ int calc_SO(Ctx &X, const soap_calc_desc &cd, double *ro
         double rp = rowbase_all[coloff[cd.parent] + SOC_r];
         float r32 = (float)rp;
         R_phys = cd.radius * (double)r32;
-        *required = R_phys;
+        // halo_prop.physical_radius_mpc = multiple * R.to("Mpc"); the scheduler converts it back
+        // (SO_properties.py:3917, halo_tasks.py:168): same two roundings as the oracle
+        *required = ((R_phys * P.a) / P.mpc) * P.mpc / P.a;
         float chk = (float)cd.radius * r32;
         if ((double)chk > Rcur) return RES_TOO_SMALL;
     } else if (cd.kind == SOAP_CALC_SO_PHYSICAL) {
@@ -1333,6 +1335,7 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
     if (!cfg || !out) return fail(-1, "null argument");
     if (cfg->abi_version != SOAP_ENGINE_ABI_VERSION) return fail(-2, "ABI version mismatch");
     if (!(cfg->boxsize > 0.0)) return fail(-3, "boxsize must be positive");
+    if (!(cfg->a > 0.0) || !(cfg->mpc > 0.0)) return fail(-3, "a and mpc must be positive");
     int ndev = 0;
     HIPCHECK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(-4, "no HIP device: the engine has no CPU fallback");
@@ -1590,6 +1593,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.halo.index = h->d_index; P.halo.is_central = h->d_central; P.halo.nr_bound = h->d_nrbound;
     P.halo.status = h->d_status; P.halo.stats = h->d_stats; P.halo.todo = nullptr; P.halo.n_todo = 0;
     P.boxsize = h->cfg.boxsize; P.G_eff = h->cfg.G_eff; P.nu_density = h->cfg.nu_density; P.mpc20 = h->cfg.mpc20;
+    P.a = h->cfg.a; P.mpc = h->cfg.mpc;
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;

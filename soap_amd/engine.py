@@ -60,7 +60,7 @@ class Engine:
     """One GPU's halo-property engine (one handle = one chunk at a time)."""
 
     def __init__(self, boxsize, G_eff, softening, nu_density=0.0, mpc20=float("inf"),
-                 device=0, n_workgroups=0, slab_capacity=0):  # fmt: skip
+                 a=1.0, mpc=1.0, device=0, n_workgroups=0, slab_capacity=0):  # fmt: skip
         self._lib = _lib.load()
         cfg = EngineConfig()
         cfg.abi_version = _lib.ABI_VERSION
@@ -69,6 +69,8 @@ class Engine:
         cfg.G_eff = float(G_eff)
         cfg.nu_density = float(nu_density)
         cfg.mpc20 = float(mpc20)
+        cfg.a = float(a)
+        cfg.mpc = float(mpc)
         for i in range(_lib.NTYPES):
             cfg.softening[i] = float(softening[i])
         cfg.n_workgroups = int(n_workgroups)
