@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the halo-property engine (BASELINE.json).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[2], the one the north-star target is
+quoted on -- synthetic DMO chunk, 1e8 particles / 1e5 halos, BoundSubhalo + the 9 default SO
+definitions + inclusive/exclusive 30/50/100 kpc spheres (16 calculations), fp64, one chunk per
+GPU.  `--workload c2` selects configs[1] (1e7 / 1e4, SO_200_crit only).
+
+A "step" is one pass of the hot path over the chunk with the raw particle arrays already
+resident in HBM: mesh build + reorder into cell order (soap_engine_stage_particles) and
+process_halos (soap_engine_run) -- SURVEY.md section 8(d).  Multi-GPU: weak scaling, one chunk per
+rank, no data-path collective; the per-rank result tables are concatenated with ONE RCCL
+all-gather (the catalogue gather that replaces combine_chunks' parallel sort), inside the
+timed region.
+
+metric = particle-aperture evaluations per second: E = sum_h n_sel(h) * A, n_sel = particles in
+the halo's final search sphere, A = number of calculations.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+B_PARTICLE = 68  # x,y,z,vx,vy,vz,m fp64 + GroupNr_bound i32 + FOFGroupIDs i64
+
+WORKLOADS = {
+    "c3": dict(n_part=100_000_000, n_halo=100_000, so="default", apertures=(30.0, 50.0, 100.0),
+               name="synthetic DMO 1e8 particles / 1e5 halos, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc"),
+    "c2": dict(n_part=10_000_000, n_halo=10_000, so="200_crit", apertures=(),
+               name="synthetic DMO 1e7 particles / 1e4 halos, BoundSubhalo + SO_200_crit"),
+    "tiny": dict(n_part=400_000, n_halo=400, so="default", apertures=(30.0, 50.0, 100.0),
+                 name="synthetic DMO 4e5 particles / 4e2 halos (plumbing check)"),
+}  # fmt: skip
+
+
+def build_props(sc, wl):
+    from soap_amd import compute_halo_properties as chp
+    from soap_amd.core.category_filter import CategoryFilter
+
+    cf = CategoryFilter(dmo=True)
+    so_vars = None if wl["so"] == "default" else {"200_crit": {"value": 200.0, "type": "crit"}}
+    ap_vars = chp.aperture_variations(wl["apertures"]) if wl["apertures"] else {}
+    return cf, so_vars, ap_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars)
+
+
+def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
+    """Oracle (CPU restatement of the reference, one core) timed on a bounded sample of the
+    SAME chunk: the halos whose read sphere lies inside a sub-cube, with the particles of that
+    sub-cube copied to the host.  Only process_halos-equivalent work is timed."""
+    import torch
+
+    from soap_amd.core.category_filter import CategoryFilter
+    from tests import helpers
+    from oracle import halo_oracle as ho
+
+    L = sc.boxsize
+    pos = data[1]["Coordinates"]
+    n = pos.shape[0]
+    frac = min(1.0, (1.5e6 / n) ** (1.0 / 3.0))
+    side = L * frac
+    rr = halos["read_radius"]
+    c = halos["cofp"]
+    inside = ((c - rr[:, None] >= 0.0) & (c + rr[:, None] <= side)).all(dim=1)
+    rows = torch.nonzero(inside).flatten()
+    if rows.numel() == 0:
+        return None
+    psel = (pos <= side).all(dim=1)
+    d_np = {1: {k: v[psel].cpu().numpy() for k, v in data[1].items()}}
+    h_np = {k: v[rows].cpu().numpy() for k, v in halos.items()}
+    cf, so_vars, ap_vars, _ = build_props(sc, wl)
+    u, props = helpers.oracle_prop_list(sc, cf, so_vars, ap_vars)
+    npart = d_np[1]["Masses"].shape[0]
+    res = max(1, int(round(ho.mesh_resolution(n) * frac)))
+    mesh = {1: ho.Mesh(d_np[1]["Coordinates"], res)}
+    A = len(props)
+    td = ho.target_density_of(props, u)
+    t0 = time.perf_counter()
+    evals = 0
+    nh = 0
+    for i in range(len(h_np["index"])):
+        ih = {k: v[i, ...].copy() for k, v in h_np.items()}
+        st = {}
+        r = ho.process_single_halo(mesh, d_np, props, u, ih, td if ih["is_central"] == 1 else None, st)
+        if r is not None:
+            evals += st["n_sel"] * A
+            nh += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+        "halos_per_s": nh / dt,
+        "sample": f"{nh} halos of the same chunk inside a {frac:.3f}L sub-cube ({npart} particles), "
+                  f"{dt:.1f} s of NumPy oracle on 1 core; the true reference adds unyt overhead",
+    }  # fmt: skip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+
+    g.build()
+    from soap_amd.core import halo_tasks
+    from soap_amd.synthetic import make_chunk
+
+    wl = WORKLOADS[args.workload]
+    t_gen = time.time()
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed + rank, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    cf, so_vars, ap_vars, props = build_props(sc, wl)
+    A = len(props)
+    halos_np = {k: v.cpu().numpy() for k, v in halos.items()}
+    H = len(halos_np["index"])
+
+    engine = halo_tasks.make_engine(sc, device=local_rank)
+    ncols_total = None
+    gathered = None
+
+    def step():
+        nonlocal ncols_total, gathered
+        halo_tasks.stage_chunk(engine, data)
+        ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
+        out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
+        raw = out[4]
+        if world > 1:
+            # catalogue gather over xGMI: one all-gather of the (equal-sized) result tables
+            nc = engine.row_columns
+            mine = torch.empty(H * nc, dtype=torch.float64, device=f"cuda:{local_rank}")
+            engine.copy_table_to(mine)
+            gathered = torch.empty(world * H * nc, dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_gather_into_tensor(gathered, mine)
+        return raw, out[2]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ms_halo, ms_mesh, ms_reorder = [], [], []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        raw, nleft = step()
+        ms_halo.append(engine.kernel_ms("halo"))
+        ms_mesh.append(engine.kernel_ms("mesh"))
+        ms_reorder.append(engine.kernel_ms("reorder"))
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    stats = raw["stats"]
+    ok = raw["status"] == 0
+    n_sel = int(stats[ok, 1].sum())
+    n_cand = int(stats[ok, 2].sum())
+    evals = n_sel * A
+    tot = torch.tensor([evals, int(ok.sum()), n_cand], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    evals_all, halos_all, ncand_all = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        ncols = engine.row_columns
+        t_halo = float(np.mean(ms_halo)) * 1e-3
+        b_alg = n_cand * B_PARTICLE + H * ncols * 8
+        achieved = b_alg / t_halo / 1e9
+        line = {
+            "metric": "particle_aperture_evals_per_s",
+            "value": evals_all * args.steps / dt,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "particles_per_gpu": wl["n_part"],
+                       "halos_per_gpu": H, "calculations": A, "seed": args.seed,
+                       "mesh_resolution": int(halo_tasks.mesh_resolution(wl["n_part"]))},
+            "halos_per_s": halos_all * args.steps / dt,
+            "halos_unfinished": int(nleft),
+            "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
+                          "reorder": float(np.mean(ms_reorder))},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes": b_alg,
+                "note": "sum_h n_cand(h)*68 B + H*P*8 B per launch / HIP-event duration of k_halo",
+            },
+            "reorder_roofline": {
+                "achieved": 2 * wl["n_part"] * B_PARTICLE / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,
+                "unit": "GB/s", "algorithmic_bytes": 2 * wl["n_part"] * B_PARTICLE,
+            },
+            "generation_s": t_gen,
+            "phase_cycles": engine.phase_cycles(),
+            "n_loop_mean": float(stats[ok, 0].mean()), "n_sel_max": int(stats[ok, 1].max()),
+            "n_sel_sum": n_sel, "n_cand_sum": n_cand,
+        }  # fmt: skip
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(sc, data, halos, wl)
+            except Exception as e:  # the baseline must never hide the GPU number
+                line["cpu_baseline"] = {"error": repr(e)}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

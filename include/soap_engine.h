@@ -163,6 +163,11 @@ int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double
 /* device pointer of the result table (for the multi-GPU catalogue gather), or NULL */
 const double *soap_engine_table_device(const soap_engine *h);
 
+/* device-to-device copy of the result table into a caller-owned HBM buffer of
+ * n_halo*row_columns doubles (e.g. the send buffer of the RCCL catalogue all-gather that
+ * replaces combine_chunks' parallel sort, SOAP/core/combine_chunks.py:33-61) */
+int32_t soap_engine_copy_table_device(soap_engine *h, double *dst_device);
+
 /*
  * Debug/verification entry: original particle indices (positions in the staged arrays) of
  * the particles of `type_slot` whose wrapped radius about halo row `row` satisfies
@@ -176,6 +181,11 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t type_slot, d
 /* average duration in ms of the named internal kernel over the last run, measured with
  * HIP events on the engine's stream ("halo", "reorder", "mesh"); <0 if unknown */
 double soap_engine_kernel_ms(const soap_engine *h, const char *name);
+
+/* diagnostic: shader cycles (summed over workgroups, thread 0's clock) the last run spent in
+ * each phase of the halo kernel: [0] select, [1] sort, [2] materialize+cumsum, [3] moment
+ * reductions, [4] scans, [5] reserved, [6] whole halo, [7] reserved */
+int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out8);
 
 #ifdef __cplusplus
 }

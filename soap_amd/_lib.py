@@ -72,12 +72,14 @@ SYMBOLS = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "soap_engine_table_device": (C.c_void_p, [C.c_void_p]),
+    "soap_engine_copy_table_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "soap_engine_membership": (
         C.c_int64,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p,
          C.c_int64],
     ),  # fmt: skip
     "soap_engine_kernel_ms": (C.c_double, [C.c_void_p, C.c_char_p]),
+    "soap_engine_phase_cycles": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

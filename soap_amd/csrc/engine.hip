@@ -104,6 +104,7 @@ struct RunParams {
     long long ncols;
     double *table;
     unsigned *queue;
+    unsigned long long *phase;   // [8] accumulated s_memtime cycles of thread 0 per phase
     const soap_calc_desc *calcs;  // device copy
     const int *coloff;            // device: column offset per calc
 };
@@ -326,6 +327,14 @@ struct Shared {
     int flag;
 };
 
+#define PH_SELECT 0
+#define PH_SORT 1
+#define PH_MATERIALIZE 2
+#define PH_REDUCE 3
+#define PH_SCAN 4
+#define PH_SO 5
+#define PH_TOTAL 6
+
 struct Ctx {
     const RunParams *P;
     Shared *S;
@@ -339,7 +348,16 @@ struct Ctx {
     unsigned char *flags;
     long long cap;
     int n;          // selected particles this round
+    unsigned long long *phase;
     double shift[3];
+};
+
+struct PhaseTimer {
+    unsigned long long t0;
+    const Ctx &X;
+    int ph;
+    __device__ PhaseTimer(const Ctx &x, int p) : X(x), ph(p) { t0 = (x.tid == 0) ? __builtin_readcyclecounter() : 0ull; }
+    __device__ ~PhaseTimer() { if (X.tid == 0) atomicAdd(&X.phase[ph], (unsigned long long)(__builtin_readcyclecounter() - t0)); }
 };
 
 // selection predicate over the sorted slab
@@ -355,6 +373,7 @@ SOAP_DEV bool member(const Ctx &X, const Pred &pr, int i, unsigned char fl) {
 // block-wide reduction of the moment set over a predicate; totals land in `dst` (LDS, NACC
 // doubles), valid for every thread after the trailing barrier.
 __device__ __noinline__ void reduce_moments(const Ctx &X, const Pred &pr, double *dst) {
+    PhaseTimer pt_(X, PH_REDUCE);
     double a[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; k++) a[k] = 0.0;
@@ -418,6 +437,7 @@ struct ScanOut {
 //    interpolation from the previous member
 __device__ __noinline__ void scan_pass(const Ctx &X, const Pred &pr, double target_all, double target_dm,
                           bool allclose_unsoft, ScanOut *out) {
+    PhaseTimer pt_(X, PH_SCAN);
     Shared *S = X.S;
     const double *soft = X.P->soft;
     double carryA = 0.0, carryB = 0.0, carryC = 0.0;
@@ -538,6 +558,7 @@ SOAP_DEV void cmpx_lds(Shared *S, int a, int b, bool asc) {
 
 // sort X.r / X.pidx [0, n) ascending; entries [n, npad) are padded with +inf
 __device__ __noinline__ void sort_slab(Ctx &X, int n) {
+    PhaseTimer pt_(X, PH_SORT);
     Shared *S = X.S;
     int npad = 1;
     while (npad < n) npad <<= 1;
@@ -625,6 +646,7 @@ SOAP_DEV bool mask_bit(const unsigned long long *m, int q) { return (m[q >> 6] >
 // 183-194), write (exact wrapped radius, packed index) to the slab.  Returns via LDS: nsel,
 // enclosed mass, n_cand.  overflow -> S->flag |= 1
 __device__ __noinline__ void select_particles(Ctx &X, double R, double *mass_out, long long *ncand_out) {
+    PhaseTimer pt_(X, PH_SELECT);
     Shared *S = X.S;
     const RunParams &P = *X.P;
     if (X.tid == 0) { S->nsel = 0; }
@@ -706,6 +728,7 @@ __device__ __noinline__ void select_particles(Ctx &X, double R, double *mass_out
 // gather the per-particle fields into the sorted slab, build the flags and run the sequential
 // cumulative-mass pass (numpy.cumsum order: SO_properties.py:400)
 __device__ __noinline__ void materialize(Ctx &X, int n) {
+    PhaseTimer pt_(X, PH_MATERIALIZE);
     Shared *S = X.S;
     const RunParams &P = *X.P;
     if (X.tid == 0) {
@@ -1107,6 +1130,7 @@ __global__ void __launch_bounds__(BLK) k_halo(const RunParams *Pp) {
     X.tid = threadIdx.x; X.lane = threadIdx.x & 63; X.w = threadIdx.x >> 6;
     X.L = P.boxsize;
     X.cap = P.slab.cap;
+    X.phase = P.phase;
     const long long so = (long long)blockIdx.x * P.slab.cap;
     X.r = P.slab.r + so; X.m = P.slab.m + so; X.dx = P.slab.dx + so; X.dy = P.slab.dy + so;
     X.dz = P.slab.dz + so; X.vx = P.slab.vx + so; X.vy = P.slab.vy + so; X.vz = P.slab.vz + so;
@@ -1120,6 +1144,7 @@ __global__ void __launch_bounds__(BLK) k_halo(const RunParams *Pp) {
         __syncthreads();
         if (task >= ntask) break;
         const long long hrow = P.halo.todo ? P.halo.todo[task] : task;
+        PhaseTimer pt_total(X, PH_TOTAL);
         X.c[0] = P.halo.cofp[3 * hrow]; X.c[1] = P.halo.cofp[3 * hrow + 1]; X.c[2] = P.halo.cofp[3 * hrow + 2];
         X.hindex = P.halo.index[hrow];
         const double Rread = P.halo.read_radius[hrow];
@@ -1281,6 +1306,8 @@ struct soap_engine {
     int *d_coloff = nullptr;
     unsigned *d_queue = nullptr;
     RunParams *d_params = nullptr;
+    unsigned long long *d_phase = nullptr;
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // slabs
     long long slab_cap = 0;
     int slab_wgs = 0;
@@ -1348,6 +1375,7 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
     HIPCHECK(hipEventCreate(&h->ev1));
     HIPCHECK(hipMalloc((void **)&h->d_queue, sizeof(unsigned)));
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
+    HIPCHECK(hipMalloc((void **)&h->d_phase, 8 * sizeof(unsigned long long)));
     *out = h;
     return 0;
 }
@@ -1374,6 +1402,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_coloff) (void)hipFree(h->d_coloff);
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1597,6 +1626,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
+    P.phase = h->d_phase;
+    HIPCHECK(hipMemsetAsync(h->d_phase, 0, 8 * sizeof(unsigned long long), st));
 
     std::vector<int> status(h->n_halo);
     std::vector<int> todo;
@@ -1631,11 +1662,21 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         P.halo.n_todo = (long long)todo.size();
     }
     h->ms_halo = ms_total;
+    HIPCHECK(hipMemcpy(h->phase, h->d_phase, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
 int64_t soap_engine_row_columns(const soap_engine *h) { return h ? h->ncols : -1; }
 const double *soap_engine_table_device(const soap_engine *h) { return h ? h->d_table : nullptr; }
+
+int32_t soap_engine_copy_table_device(soap_engine *h, double *dst) {
+    if (!h || !dst) return fail(-1, "null argument");
+    if (!h->d_table) return fail(-2, "no run to copy");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    HIPCHECK(hipMemcpyAsync(dst, h->d_table, (size_t)h->n_halo * h->ncols * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
 
 int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double *search_radius,
                           double *read_radius, int64_t *stats) {
@@ -1690,6 +1731,12 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t ts, double r
     (void)hipFree(d_cnt);
     if (d_out) (void)hipFree(d_out);
     return (int64_t)cnt;
+}
+
+int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out8) {
+    if (!h || !out8) return fail(-1, "null argument");
+    for (int i = 0; i < 8; i++) out8[i] = h->phase[i];
+    return 0;
 }
 
 double soap_engine_kernel_ms(const soap_engine *h, const char *name) {

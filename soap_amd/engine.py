@@ -164,6 +164,12 @@ class Engine:
             )
         return dict(table=table, status=status, search_radius=search, read_radius=read, stats=stats)
 
+    def copy_table_to(self, tensor):
+        """Device-to-device copy of the result table into a torch CUDA float64 tensor."""
+        if tensor.numel() != self.n_halo * self.row_columns or not tensor.is_cuda:
+            raise ValueError("need a CUDA float64 tensor of n_halo*row_columns elements")
+        self._check(self._lib.soap_engine_copy_table_device(self._h, C.c_void_p(tensor.data_ptr())))
+
     def table_device_ptr(self):
         return self._lib.soap_engine_table_device(self._h)
 
@@ -178,6 +184,12 @@ class Engine:
         if n > cap:
             return self.membership(row, type_slot, radius, strict, bound_only, cap=int(n))
         return out[:n].copy()
+
+    def phase_cycles(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.soap_engine_phase_cycles(self._h, out))
+        names = ("select", "sort", "materialize", "reduce", "scan", "_5", "total", "_7")
+        return {n: int(v) for n, v in zip(names, out) if not n.startswith("_")}
 
     def kernel_ms(self, name: str) -> float:
         return float(self._lib.soap_engine_kernel_ms(self._h, name.encode()))
