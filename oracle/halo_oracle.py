@@ -129,6 +129,17 @@ def flamingo_like_units(boxsize: float = 100.0) -> Units:
 # --------------------------------------------------------------------------
 # L0 kernels
 # --------------------------------------------------------------------------
+def _qpow(x, p):
+    """
+    `x**p` for a unyt QUANTITY.  In the reference these are 0-d arrays, so the power goes
+    through NumPy's array loop (a SIMD pow on AVX-512/AVX2 hosts) and not through the scalar
+    libm pow that a bare np.float64 would use; the two differ in the last bit for a few per
+    cent of arguments.  Mirrored here so that golden vectors generated from the reference
+    match bit-for-bit on the same host.
+    """
+    return np.power(np.asarray(x, dtype=np.float64), p)[()]
+
+
 def cumulative_mass_intersection(r, rho_dim, slope_dim):
     """SO_properties.py:50-77"""
     return 4.0 * np.pi / 3.0 * rho_dim * r**3 - slope_dim * r + slope_dim - 1.0
@@ -162,7 +173,7 @@ def find_SO_radius_and_mass(
             0.75 * cumulative_mass[ipos] / (np.pi * ordered_radius[ipos] * reference_density)
         )
         SO_mass = cumulative_mass[ipos] * SO_r / ordered_radius[ipos]
-        return SO_r, SO_mass, 4.0 * np.pi / 3.0 * SO_r**3
+        return SO_r, SO_mass, 4.0 * np.pi / 3.0 * _qpow(SO_r, 3)
 
     r1 = ordered_radius[i - 1]
     r2 = ordered_radius[i]
@@ -181,10 +192,10 @@ def find_SO_radius_and_mass(
         M1 = M2
         M2 = cumulative_mass[i]
 
-    rho_dim = reference_density * r1**3 / M1
+    rho_dim = reference_density * _qpow(r1, 3) / M1
     slope_dim = (M2 - M1) / (r2 - r1) * (r1 / M1)
     SO_r = r1 * brentq(cumulative_mass_intersection, 1.0, r2 / r1, args=(rho_dim, slope_dim))
-    SO_volume = 4.0 / 3.0 * np.pi * SO_r**3
+    SO_volume = 4.0 / 3.0 * np.pi * _qpow(SO_r, 3)
     SO_mass = SO_volume * reference_density
     return SO_r, SO_mass, SO_volume
 
@@ -706,7 +717,7 @@ class SOProperties:
                     raise SearchRadiusTooSmallError("SO radius multiple was too small!")
         elif physical_radius > 0:
             SO_r = physical_radius
-            SO_volume = 4.0 * np.pi / 3.0 * SO_r**3
+            SO_volume = 4.0 * np.pi / 3.0 * _qpow(SO_r, 3)
             if nr_parts > 0:
                 outside_radius = ordered_radius > SO_r
                 if not np.any(outside_radius):
@@ -777,8 +788,8 @@ class SOProperties:
                 # calculate_concentration (SO_properties.py:2738-2753), no nu particles
                 R1 = np.sum(mass * rr)
                 missed_mass = SO_mass - np.sum(mass)
-                R1 += np.pi * u.nu_density_comoving * SO_r**4
-                missed_mass -= u.nu_density_comoving * 4.0 / 3.0 * np.pi * SO_r**3
+                R1 += np.pi * u.nu_density_comoving * _qpow(SO_r, 4)
+                missed_mass -= u.nu_density_comoving * 4.0 / 3.0 * np.pi * _qpow(SO_r, 3)
                 R1 += missed_mass * SO_r
                 R1 /= SO_r * SO_mass
                 out[key] = concentration_from_R1(R1)
@@ -1091,7 +1102,7 @@ def process_single_halo(mesh, data, halo_prop_list, units: Units, input_halo, ta
             ncand += nc
             if ptype in PTYPES_FOR_SO_MASSES:
                 mass_total += np.sum(data[ptype]["Masses"][idx[ptype]], dtype=float)
-        density = mass_total / (4.0 / 3.0 * np.pi * current_radius**3)
+        density = mass_total / (4.0 / 3.0 * np.pi * _qpow(current_radius, 3))
         max_physical_radius_mpc = 0.0
         if target_density is None or density <= target_density:
             particle_data = {}

@@ -1,0 +1,87 @@
+"""
+Final-catalogue concatenation across GPUs: the one exchange step of the path.
+
+The reference writes per-chunk scratch files and then `combine_chunks` does a distributed
+sort of all halos by (SWIFT cell of the halo centre, catalogue index)
+(SOAP/core/combine_chunks.py:33-61, `spatial_sort`) and `fetch_elements` per property.
+Here every rank (one per GPU) holds its chunk's fp64 result table in HBM; ONE all-gather
+(RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests) concatenates the tables
+and the halo keys, and every rank applies the same ordering rule locally.  No reduction is
+needed: halos are independent.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def spatial_sort_order(halo_cofp: np.ndarray, halo_index: np.ndarray, cell_size, dimension):
+    """Order of the final catalogue: by cell index ix*dim0^2 + iy*dim1 + iz, then by
+    catalogue index (combine_chunks.py:38-52)."""
+    cell_indices = (np.asarray(halo_cofp) // np.asarray(cell_size)).astype("int64")
+    assert dimension[0] >= dimension[1] >= dimension[2]
+    if cell_indices.shape[0] > 0:
+        assert np.min(cell_indices) >= 0
+        for i_cell in range(3):
+            assert np.max(cell_indices[:, i_cell]) < dimension[i_cell]
+    cell_index = (cell_indices[:, 0] * dimension[0] ** 2 + cell_indices[:, 1] * dimension[1]
+                  + cell_indices[:, 2])  # fmt: skip
+    return np.lexsort((np.asarray(halo_index, dtype=np.int64), cell_index))
+
+
+def gather_catalogue(table: torch.Tensor, cofp: torch.Tensor, index: torch.Tensor, cell_size,
+                     dimension, group=None):  # fmt: skip
+    """
+    table [n_local, ncols] float64, cofp [n_local, 3] float64, index [n_local] int64, all on
+    this rank's device.  Ranks may hold different numbers of halos: rows are padded to the
+    maximum for the (single) all-gather and the padding is dropped afterwards.
+    Returns (table_all, cofp_all, index_all) in final-catalogue order, identical on all ranks.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_local, ncols = table.shape
+    dev = table.device
+    if world == 1:
+        order = spatial_sort_order(cofp.cpu().numpy(), index.cpu().numpy(), cell_size, dimension)
+        o = torch.as_tensor(order, device=dev)
+        return table[o], cofp[o], index[o]
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    nmax = int(counts.max().item())
+    # one payload row per halo: [catalogue index bits | cofp(3) | table row], padded to nmax rows
+    payload = torch.zeros((nmax, ncols + 4), dtype=torch.float64, device=dev)
+    payload[:n_local, 0] = index.to(torch.int64).view(torch.float64) if index.dtype == torch.int64 else index
+    payload[:n_local, 1:4] = cofp
+    payload[:n_local, 4:] = table
+    gathered = torch.empty((world * nmax, ncols + 4), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(gathered, payload, group=group)
+    keep = torch.cat([torch.arange(int(c), device=dev) + r * nmax for r, c in enumerate(counts.tolist())])
+    gathered = gathered[keep]
+    index_all = gathered[:, 0].contiguous().view(torch.int64)
+    cofp_all = gathered[:, 1:4]
+    order = spatial_sort_order(cofp_all.cpu().numpy(), index_all.cpu().numpy(), cell_size, dimension)
+    o = torch.as_tensor(order, device=dev)
+    return gathered[o, 4:], cofp_all[o], index_all[o]
+
+
+def partition_halos(cofp: np.ndarray, n_chunks: int, boxsize: float, bits: int = 10):
+    """
+    Assign halos to `n_chunks` spatially compact, equal-count chunks by sorting the centres
+    along a space-filling curve, as the reference's Peano-Hilbert decomposition does
+    (SOAP/core/domain_decomposition.py:64-142; its key comes from virgo.util.peano, which is
+    not in the reference tree -- we use a Morton key of the same 10 bits per dimension: chunk
+    membership differs from the reference's, per-halo results do not depend on it).
+    Returns chunk id per halo.
+    """
+    n = cofp.shape[0]
+    ipos = np.clip((cofp / boxsize * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    key = np.zeros(n, dtype=np.int64)
+    for b in range(bits):
+        for d in range(3):
+            key |= ((ipos[:, d] >> b) & 1) << (3 * b + (2 - d))
+    order = np.argsort(key, kind="stable")
+    chunk = np.empty(n, dtype=np.int64)
+    chunk[order] = (np.arange(n) * n_chunks) // max(n, 1)
+    return chunk

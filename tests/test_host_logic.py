@@ -1,0 +1,111 @@
+"""Host-side mirror of the reference's operator surface: names, density bookkeeping, calc
+descriptors, filters, unit factors (no GPU needed)."""
+
+import numpy as np
+import pytest
+
+from oracle import halo_oracle as ho
+from soap_amd import compute_halo_properties as chp
+from soap_amd import layout
+from soap_amd.core import halo_tasks
+from soap_amd.core.category_filter import CategoryFilter
+from soap_amd.particle_selection import SO_properties, aperture_properties
+from soap_amd.particle_selection.halo_properties import SearchRadiusTooSmallError
+from soap_amd.property_table import full_property_list, stored_value
+from soap_amd.synthetic import make_chunk, to_numpy
+from soap_amd.units import SnapshotScalars
+from tests import helpers
+
+
+def test_unit_factors_are_bitwise_those_of_the_oracle():
+    sc = SnapshotScalars(boxsize=215.4)
+    u = helpers.oracle_units(sc)
+    for r in (30.0, 50.0, 100.0, 0.5, 3000.0):
+        assert sc.kpc_to_comoving(r) == u.kpc_to_comoving(r)
+        assert sc.mpc_to_comoving(r) == u.mpc_to_comoving(r)
+    assert sc.G_eff == u.G_eff and sc.softening_comoving() == u.softening_comoving(1)
+    assert sc.virBN98 == pytest.approx(ho.flamingo_like_units().virBN98, rel=1e-15)
+    for mult in (50.0, 200.0, 2500.0):
+        assert sc.density_to_comoving(mult * sc.critical_density) == u.density_to_comoving(mult * u.critical_density)
+
+
+def test_halo_prop_list_order_names_and_densities():
+    sc = SnapshotScalars()
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((100.0, 30.0, 50.0)))
+    names = [p.name for p in props]
+    assert names[0] == "bound_subhalo"
+    assert names[1:10] == ["SO_200_mean", "SO_50_crit", "SO_100_crit", "SO_200_crit", "SO_500_crit",
+                           "SO_1000_crit", "SO_2500_crit", "SO_BN98", "SO_5xR_500_crit"]  # fmt: skip
+    # apertures sorted by radius, inclusive and exclusive interleaved in dict order
+    assert [p.group_name for p in props[10:]] == [
+        "InclusiveSphere/30kpc", "ExclusiveSphere/30kpc", "InclusiveSphere/50kpc",
+        "ExclusiveSphere/50kpc", "InclusiveSphere/100kpc", "ExclusiveSphere/100kpc"]  # fmt: skip
+    so200c = props[4]
+    assert so200c.group_name == "SO/200_crit" and so200c.virial_definition
+    assert so200c.mean_density_multiple == 1000.0 and so200c.critical_density_multiple == 200.0
+    assert props[8].group_name == "SO/BN98" and props[9].group_name == "SO/5xR_500_crit"
+    # same target density as the oracle's scheduler (halo_tasks.py:306-317)
+    u, oprops = helpers.oracle_prop_list(sc, cf, None, chp.aperture_variations((100.0, 30.0, 50.0)))
+    assert halo_tasks.target_density_of(props, sc) == ho.target_density_of(oprops, u)
+    assert [p.name for p in oprops] == names
+    assert [p.group_name for p in oprops] == [p.group_name for p in props]
+
+
+def test_calc_descriptors():
+    sc = SnapshotScalars()
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"500_crit": {"value": 500.0, "type": "crit", "filter": "general"},
+               "5xR500_crit": {"value": 500.0, "type": "crit", "radius_multiple": 5.0}}  # fmt: skip
+    props = chp.build_halo_prop_list(sc, cf, so_vars, chp.aperture_variations((30.0, 50.0)))
+    descs = [p.calc_desc(props, i) for i, p in enumerate(props)]
+    assert [d.kind for d in descs] == [0, 1, 3, 4, 5, 4, 5]
+    assert descs[1].filter_limit == 100 and descs[1].filter_types == 0b0010  # DMO: only DM counted
+    assert descs[2].parent == 1 and descs[2].radius == 5.0
+    assert descs[4].parent == -1 and descs[6].parent == 4  # exclusive 50 kpc copies from exclusive 30 kpc
+    assert descs[5].parent == -1  # inclusive spheres never skip by default (compute_halo_properties.py:365-370)
+    assert descs[6].prev_radius == sc.kpc_to_comoving(30.0)
+    assert descs[3].physical_radius_mpc == sc.mpc_to_comoving(0.03)
+    with pytest.raises(RuntimeError):
+        SO_properties.RadiusMultipleSOProperties(sc, None, None, cf, "basic", 200.0, 5.0, "crit").calc_desc(props, 3)
+    with pytest.raises(AttributeError):
+        SO_properties.SOProperties(sc, None, None, cf, "basic", 200.0, "median")
+    assert issubclass(SearchRadiusTooSmallError, Exception)
+
+
+def test_category_filter_matches_reference_semantics():
+    cf = CategoryFilter(dmo=False)
+    hr = {"BoundSubhalo/NumberOfDarkMatterParticles": (np.array([60], dtype=np.uint32),),
+          "BoundSubhalo/NumberOfGasParticles": (np.array([50], dtype=np.uint32),),
+          "BoundSubhalo/NumberOfStarParticles": (np.array([3], dtype=np.uint32),),
+          "BoundSubhalo/NumberOfBlackHoleParticles": (np.array([0], dtype=np.uint32),)}  # fmt: skip
+    do = cf.get_do_calculation(hr)
+    assert do == {"basic": True, "general": True, "dm": False, "gas": False, "star": False, "baryon": False}
+    do = CategoryFilter(dmo=True).get_do_calculation(hr)
+    assert do["general"] is False and do["dm"] is False
+    assert CategoryFilter(dmo=False).engine_filter("baryon") == (100, 0b0101)
+    assert CategoryFilter().engine_filter("basic") == (0, 0)
+
+
+def test_stored_value_casts_once():
+    a = 0.5
+    v = stored_value("Ldm", np.array([1.0, 2.0, 1e-3]), a)
+    assert v.dtype == np.float32 and np.array_equal(v, np.float32(np.array([0.5, 1.0, 5e-4])))
+    assert stored_value("Ndm", np.array([12345.0]), a).dtype == np.uint32
+    assert stored_value("com", np.array([1.0, 2.0, 3.0]), a).dtype == np.float64
+    for key, prop in full_property_list.items():
+        assert prop.shape in (1, 3, 6)
+
+
+def test_synthetic_chunk_is_self_consistent():
+    sc, data, halos = make_chunk(30000, 25, seed=2)
+    d, h = to_numpy(data, halos)
+    assert np.all(np.diff(h["nr_bound_part"]) <= 0)  # processing order: largest first
+    grnr = d[1]["GroupNr_bound"]
+    for row in range(len(h["index"])):
+        assert (grnr == h["index"][row]).sum() == h["nr_bound_part"][row]
+    # one particle sits exactly on every halo centre
+    pos = d[1]["Coordinates"]
+    for c in h["cofp"][:5]:
+        assert np.any(np.all(pos == c, axis=1))
+    assert pos.min() >= 0 and pos.max() < sc.boxsize

@@ -1,0 +1,63 @@
+"""
+N>1 path on CPU: two gloo ranks, each with its own part of the halo table, gather the
+catalogue and must end up with the same, correctly ordered concatenation
+(SOAP/core/combine_chunks.py:33-61 ordering rule).
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from soap_amd.catalogue import gather_catalogue, partition_halos, spatial_sort_order
+
+    rng = np.random.default_rng(99)
+    n, ncols, L = 137, 11, 100.0
+    cofp = rng.uniform(0, L, (n, 3))
+    index = rng.permutation(n).astype(np.int64) * 3 + 1
+    table = rng.normal(size=(n, ncols))
+    chunk = partition_halos(cofp, world, L)
+    mine = chunk == rank
+    assert 0 < mine.sum() < n
+    t, c, i = gather_catalogue(torch.from_numpy(table[mine]), torch.from_numpy(cofp[mine]),
+                               torch.from_numpy(index[mine]), cell_size=L / 4, dimension=(4, 4, 4))  # fmt: skip
+    order = spatial_sort_order(cofp, index, L / 4, (4, 4, 4))
+    assert np.array_equal(i.numpy(), index[order])
+    assert np.array_equal(c.numpy(), cofp[order])
+    assert np.array_equal(t.numpy(), table[order])
+    np.save(os.path.join(tmpdir, f"ok{rank}.npy"), i.numpy())
+    dist.destroy_process_group()
+
+
+def test_catalogue_gather_two_ranks(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = np.load(tmp_path / "ok0.npy")
+    b = np.load(tmp_path / "ok1.npy")
+    assert np.array_equal(a, b) and len(a) == 137
+
+
+def test_partition_is_balanced_and_compact():
+    sys.path.insert(0, ROOT)
+    from soap_amd.catalogue import partition_halos
+
+    rng = np.random.default_rng(5)
+    cofp = rng.uniform(0, 50.0, (8000, 3))
+    chunk = partition_halos(cofp, 8, 50.0)
+    counts = np.bincount(chunk, minlength=8)
+    assert counts.min() == counts.max() == 1000
+    # compact: the mean extent of a chunk is well below the box size
+    ext = np.mean([np.ptp(cofp[chunk == k], axis=0).mean() for k in range(8)])
+    assert ext < 0.8 * 50.0
