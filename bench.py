@@ -223,7 +223,11 @@ def main():
             "halos_per_s": halos_all * args.steps / dt,
             "halos_unfinished": int(nleft),
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
-                          "reorder": float(np.mean(ms_reorder))},
+                          "reorder": float(np.mean(ms_reorder)),
+                          "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),
+                          "halo_wg1024": engine.kernel_ms("halo_wg1024")},
+            "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
+                                int(engine.kernel_ms("n_wg1024"))],
             "roofline": {
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

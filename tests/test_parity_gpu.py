@@ -183,7 +183,11 @@ def test_small_slab_triggers_retry_path(built_library):
     e1, ha1, r1, o1 = _run_engine(sc, data_np, halos_np, props, slab_capacity=256, n_workgroups=16)
     e2, ha2, r2, o2 = _run_engine(sc, data_np, halos_np, props)
     assert np.all(ha1["done"] == 1)
-    assert np.array_equal(o1[4]["table"], o2[4]["table"])
+    # different thread-group sizes sum in different orders: equal to rounding, counts exactly
+    t1, t2 = o1[4]["table"], o2[4]["table"]
+    assert np.allclose(t1, t2, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(t1[:, 6], t2[:, 6]) and np.array_equal(t1[:, 31 + 3], t2[:, 31 + 3])
+    assert np.array_equal(o1[4]["stats"], o2[4]["stats"])
     e1.close()
     e2.close()
 
