@@ -42,7 +42,7 @@
 #define CH 4096            // LDS sort chunk (elements)
 #define PIDX_BITS 30
 #define PIDX_MASK ((1u << PIDX_BITS) - 1u)
-#define MAXCALC 48
+#define MAXCALC 32
 
 // flags byte of a slab element
 #define FL_TYPE 0x3
@@ -701,7 +701,7 @@ static long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1
 int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_calcs,
                         double target_density) {
     if (!h) return fail(-1, "null handle");
-    if (n_calcs < 1 || n_calcs > MAXCALC) return fail(-2, "number of calculations must be in [1,48]");
+    if (n_calcs < 1 || n_calcs > MAXCALC) return fail(-2, "number of calculations must be in [1,32]");
     if (!calcs) return fail(-3, "null calcs");
     if (calcs[0].kind != SOAP_CALC_SUBHALO)
         return fail(-4, "the first calculation must be the bound subhalo (compute_halo_properties.py:232-247)");
