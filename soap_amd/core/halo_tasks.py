@@ -120,7 +120,7 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     )  # fmt: skip
     t0_task = time.time()
     engine.run(calcs, target_density)
-    out = engine.fetch()
+    out = engine.fetch(table=unpack)
     task_time = time.time() - t0_task
 
     status = out["status"]

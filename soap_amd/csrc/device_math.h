@@ -11,6 +11,15 @@
 // Used for the periodic wrap of SOAP/core/halo_tasks.py:113-117 and the centre-of-mass
 // re-wrap of SO_properties.py:562-564.
 SOAP_DEV double np_mod(double a, double b) {
+    // fast paths, exact: for b > 0 and -b < a < 2b the IEEE remainder is a, a - b (Sterbenz) or a
+    if (b > 0.0) {
+        if (a >= 0.0) {
+            if (a < b) return a;
+            if (a < 2.0 * b) return a - b;
+        } else if (a > -b) {
+            return a + b;   // fmod(a, b) = a (negative, nonzero) and NumPy then adds b
+        }
+    }
     double m = fmod(a, b);
     if (m != 0.0) {
         if ((b < 0.0) != (m < 0.0)) m += b;

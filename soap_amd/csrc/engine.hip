@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "../../include/soap_engine.h"
 #include "device_math.h"
@@ -101,6 +102,7 @@ struct RunParams {
     HaloDev halo;
     double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
     int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
+    double first_factor;   // first sorted superset reaches first_factor * search_radius
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -319,8 +321,9 @@ enum {
 // compiler and outstanding memory operations have to be fenced
 #define GRP 64
 #define GNW 1
-#define GWG 256
+#define GWG 64
 #define GCH 1024
+#define GLB 4
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 namespace g64 {
 #include "halo_kernel.inc"
@@ -329,12 +332,14 @@ namespace g64 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef GLB
 #undef GSYNC
 
 #define GRP 256
 #define GNW 4
 #define GWG 256
 #define GCH 4096
+#define GLB 4
 #define GSYNC() __syncthreads()
 namespace g256 {
 #include "halo_kernel.inc"
@@ -343,12 +348,14 @@ namespace g256 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef GLB
 #undef GSYNC
 
 #define GRP 1024
 #define GNW 16
 #define GWG 1024
-#define GCH 4096
+#define GCH 8192
+#define GLB 4
 #define GSYNC() __syncthreads()
 namespace g1024 {
 #include "halo_kernel.inc"
@@ -357,6 +364,7 @@ namespace g1024 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef GLB
 #undef GSYNC
 
 // brute-force membership list for verification (same arithmetic as the property kernels)
@@ -382,6 +390,20 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Size-keyed cache of device allocations: hipMalloc/hipFree of multi-GB buffers cost milliseconds
+// each and would dominate a staging call that is repeated for every chunk.
+struct DevPool {
+    std::multimap<size_t, void *> free_blocks;
+    hipError_t alloc(void **p, size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        auto it = free_blocks.find(bytes);
+        if (it != free_blocks.end()) { *p = it->second; free_blocks.erase(it); return hipSuccess; }
+        return hipMalloc(p, bytes);
+    }
+    void release(void *p, size_t bytes) { if (p) free_blocks.emplace(bytes == 0 ? 8 : bytes, p); }
+    void purge() { for (auto &kv : free_blocks) (void)hipFree(kv.second); free_blocks.clear(); }
+};
+
 struct TypeHost {
     long long n = 0;
     int res = 0;
@@ -392,9 +414,14 @@ struct TypeHost {
     long long *g64 = nullptr, *fof = nullptr;
     unsigned *orig = nullptr, *cell_offset = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
-    void release() {
-        void *ptrs[] = {x, y, z, vx, vy, vz, m, g32, g64, fof, orig, cell_offset};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
+    void release(DevPool &pool) {
+        void *d8[] = {x, y, z, vx, vy, vz, m};
+        for (void *p : d8) pool.release(p, (size_t)n * 8);
+        pool.release(g32, (size_t)n * 4);
+        pool.release(g64, (size_t)n * 8);
+        pool.release(fof, (size_t)n * 8);
+        pool.release(orig, (size_t)n * 4);
+        pool.release(cell_offset, ((size_t)res * res * res + 1) * 4);
         *this = TypeHost();
     }
 };
@@ -402,6 +429,7 @@ struct TypeHost {
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
+    DevPool pool;
     TypeHost t[SOAP_NTYPES];
     // halos
     long long n_halo = 0;
@@ -524,7 +552,8 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    for (int t = 0; t < SOAP_NTYPES; t++) h->t[t].release();
+    for (int t = 0; t < SOAP_NTYPES; t++) h->t[t].release(h->pool);
+    h->pool.purge();
     free_halos(h);
     free_slabs(h);
     for (int k = 0; k < 3; k++) {
@@ -558,21 +587,22 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     if (resolution < 1 || resolution > 256) return fail(-5, "mesh resolution must be in [1,256]");
     HIPCHECK(hipSetDevice(h->cfg.device));
     TypeHost &T = h->t[ts];
-    T.release();
+    DevPool &pool = h->pool;
+    T.release(pool);
     if (n == 0) return 0;   // SharedMesh.empty (shared_mesh.py:25-27)
     if (!pos || !vel || !mass || !grnr || !fof) return fail(-6, "null particle array");
     hipStream_t st = h->stream;
     const double *dpos = pos, *dvel = vel, *dmass = mass;
     const void *dgr = grnr;
     const long long *dfof = (const long long *)fof;
-    std::vector<void *> tmp;
+    std::vector<std::pair<void *, size_t>> tmp;
     if (!on_device) {
         void *a, *b, *c, *d, *e;
-        HIPCHECK(hipMalloc(&a, (size_t)n * 24)); tmp.push_back(a);
-        HIPCHECK(hipMalloc(&b, (size_t)n * 24)); tmp.push_back(b);
-        HIPCHECK(hipMalloc(&c, (size_t)n * 8)); tmp.push_back(c);
-        HIPCHECK(hipMalloc(&d, (size_t)n * grnr_bytes)); tmp.push_back(d);
-        HIPCHECK(hipMalloc(&e, (size_t)n * 8)); tmp.push_back(e);
+        HIPCHECK(pool.alloc(&a, (size_t)n * 24)); tmp.push_back({a, (size_t)n * 24});
+        HIPCHECK(pool.alloc(&b, (size_t)n * 24)); tmp.push_back({b, (size_t)n * 24});
+        HIPCHECK(pool.alloc(&c, (size_t)n * 8)); tmp.push_back({c, (size_t)n * 8});
+        HIPCHECK(pool.alloc(&d, (size_t)n * grnr_bytes)); tmp.push_back({d, (size_t)n * grnr_bytes});
+        HIPCHECK(pool.alloc(&e, (size_t)n * 8)); tmp.push_back({e, (size_t)n * 8});
         HIPCHECK(hipMemcpyAsync(a, pos, (size_t)n * 24, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(b, vel, (size_t)n * 24, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -581,18 +611,18 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
         dpos = (const double *)a; dvel = (const double *)b; dmass = (const double *)c;
         dgr = d; dfof = (const long long *)e;
     }
-    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() { for (auto &p : tmp) pool.release(p.first, p.second); tmp.clear(); };
 
     HIPCHECK(hipEventRecord(h->ev0, st));
     // bounding box (shared_mesh.py:33-61)
     const int gmm = 1024;
     double *d_partial;
-    HIPCHECK(hipMalloc((void **)&d_partial, gmm * 6 * sizeof(double)));
+    HIPCHECK(pool.alloc((void **)&d_partial, gmm * 6 * sizeof(double)));
     hipLaunchKernelGGL(k_minmax, dim3(gmm), dim3(BLK), 0, st, dpos, (long long)n, d_partial);
     std::vector<double> part(gmm * 6);
     HIPCHECK(hipMemcpyAsync(part.data(), d_partial, gmm * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    (void)hipFree(d_partial);
+    pool.release(d_partial, gmm * 6 * sizeof(double));
     for (int d = 0; d < 3; d++) { T.pos_min[d] = INFINITY; T.pos_max[d] = -INFINITY; }
     for (int b = 0; b < gmm; b++)
         for (int d = 0; d < 3; d++) {
@@ -610,11 +640,11 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     const long long ncell = (long long)resolution * resolution * resolution;
 
     unsigned *d_cell, *d_count, *d_cursor, *d_sortidx, *d_tilesum;
-    HIPCHECK(hipMalloc((void **)&d_cell, (size_t)n * 4));
-    HIPCHECK(hipMalloc((void **)&d_count, (size_t)ncell * 4));
-    HIPCHECK(hipMalloc((void **)&d_cursor, (size_t)ncell * 4));
-    HIPCHECK(hipMalloc((void **)&d_sortidx, (size_t)n * 4));
-    HIPCHECK(hipMalloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
+    HIPCHECK(pool.alloc((void **)&d_cell, (size_t)n * 4));
+    HIPCHECK(pool.alloc((void **)&d_count, (size_t)ncell * 4));
+    HIPCHECK(pool.alloc((void **)&d_cursor, (size_t)ncell * 4));
+    HIPCHECK(pool.alloc((void **)&d_sortidx, (size_t)n * 4));
+    HIPCHECK(pool.alloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
     HIPCHECK(hipMemsetAsync(d_count, 0, (size_t)ncell * 4, st));
     HIPCHECK(hipMemsetAsync(d_cursor, 0, (size_t)ncell * 4, st));
     MeshGeom g;
@@ -623,7 +653,7 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     int grid = (int)std::min<long long>((n + BLK - 1) / BLK, 256 * 8);
     hipLaunchKernelGGL(k_cellid, dim3(grid), dim3(BLK), 0, st, dpos, (long long)n, g, d_cell, d_count);
     long long ntiles = (ncell + SCAN_TILE - 1) / SCAN_TILE;
-    HIPCHECK(hipMalloc((void **)&d_tilesum, (size_t)ntiles * 4));
+    HIPCHECK(pool.alloc((void **)&d_tilesum, (size_t)ntiles * 4));
     hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, d_count, ncell, T.cell_offset, d_tilesum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.cell_offset, ncell, d_tilesum, (unsigned)n);
@@ -632,10 +662,10 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
 
     // reorder into cell order
     double **dp[] = {&T.x, &T.y, &T.z, &T.vx, &T.vy, &T.vz, &T.m};
-    for (double **p : dp) HIPCHECK(hipMalloc((void **)p, (size_t)n * 8));
-    if (T.grnr64) HIPCHECK(hipMalloc((void **)&T.g64, (size_t)n * 8));
-    else HIPCHECK(hipMalloc((void **)&T.g32, (size_t)n * 4));
-    HIPCHECK(hipMalloc((void **)&T.fof, (size_t)n * 8));
+    for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
+    if (T.grnr64) HIPCHECK(pool.alloc((void **)&T.g64, (size_t)n * 8));
+    else HIPCHECK(pool.alloc((void **)&T.g32, (size_t)n * 4));
+    HIPCHECK(pool.alloc((void **)&T.fof, (size_t)n * 8));
     hipEvent_t ev2;
     HIPCHECK(hipEventCreate(&ev2));
     hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLK), 0, st, d_sortidx, (long long)n, dpos, dvel,
@@ -652,7 +682,8 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     h->ms_mesh = ms1;
     h->ms_reorder = ms2;
     T.orig = d_sortidx;   // original index of the particle now at position p
-    (void)hipFree(d_cell); (void)hipFree(d_count); (void)hipFree(d_cursor); (void)hipFree(d_tilesum);
+    pool.release(d_cell, (size_t)n * 4); pool.release(d_count, (size_t)ncell * 4);
+    pool.release(d_cursor, (size_t)ncell * 4); pool.release(d_tilesum, (size_t)ntiles * 4);
     cleanup();
     return 0;
 }
@@ -758,6 +789,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.boxsize = h->cfg.boxsize; P.G_eff = h->cfg.G_eff; P.nu_density = h->cfg.nu_density; P.mpc20 = h->cfg.mpc20;
     P.a = h->cfg.a; P.mpc = h->cfg.mpc;
     { const char *e = getenv("SOAP_ENGINE_LITERAL"); P.literal = (e && e[0] == '1') ? 1 : 0; }
+    // radius the loop is expected to end at, in units of the catalogue search radius: a 5xR500 multiple
+    // needs ~3.3-4 R200, density thresholds down to 50 rho_crit ~2 R200 (halo_tasks.py:184-187 steps of 1.2)
+    P.first_factor = 1.2 * 1.2;
+    for (int c = 0; c < n_calcs; c++) {
+        if (calcs[c].kind == SOAP_CALC_SO_DENSITY) P.first_factor = std::max(P.first_factor, 2.0736);
+        if (calcs[c].kind == SOAP_CALC_SO_MULTIPLE) P.first_factor = std::max(P.first_factor, 0.86 * calcs[c].radius);
+    }
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
@@ -768,8 +806,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // three classes of halos by bound-particle count: one wavefront, 256 threads, 1024 threads per halo.
     // A halo whose search sphere outgrows its class' slab is retried in the next class.
     const long long nb_small = 256, nb_medium = 16384;
-    long long caps[3] = {1ll << 14, 1ll << 17, 1ll << 20};
-    int groups[3] = {2048, 512, 128};
+    long long caps[3] = {1ll << 15, 1ll << 18, 1ll << 20};
+    int groups[3] = {2816, 768, 128};
     if (h->cfg.slab_capacity > 0) {
         long long c0 = next_pow2(h->cfg.slab_capacity);
         caps[0] = c0; caps[1] = c0 * 8; caps[2] = c0 * 64;
@@ -787,30 +825,35 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
-        for (int k = 2; k >= 0; k--) {
+        // launch order: the 1024-thread class (few, long halos) on its own stream; the 256-thread class and
+        // the wavefront class share a second stream (ROCm maps streams onto few hardware queues: two
+        // user streams get distinct queues, three do not)
+        const int order[3] = {2, 1, 0};   // submission order; classes 2 and 0 share a stream
+        for (int oi = 0; oi < 3; oi++) {
+            const int k = order[oi];
             soap_engine::Class &C = h->cls[k];
+            hipStream_t cs = (k == 1) ? h->cls[0].stream : h->cls[2].stream;   // 1024-thread class, then wavefront class | 256-thread class
             if (todo[k].empty()) continue;
             any = true;
             int ng = (int)std::min<long long>(groups[k], (long long)todo[k].size());
-            const int gpw = (k == 0) ? 4 : 1;   // groups per workgroup
-            int nwg = (ng + gpw - 1) / gpw;
-            int rc = alloc_slab(C, caps[k], nwg * gpw);
+            int nwg = ng;
+            int rc = alloc_slab(C, caps[k], groups[k]);
             if (rc) return rc;
             if (C.todo_cap < (long long)todo[k].size()) {
                 if (C.d_todo) (void)hipFree(C.d_todo);
                 C.todo_cap = std::max<long long>((long long)todo[k].size(), h->n_halo);
                 HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
             }
-            HIPCHECK(hipStreamWaitEvent(C.stream, h->ev0, 0));
-            HIPCHECK(hipMemcpyAsync(C.d_todo, todo[k].data(), todo[k].size() * 4, hipMemcpyHostToDevice, C.stream));
-            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), C.stream));
+            HIPCHECK(hipStreamWaitEvent(cs, h->ev0, 0));
+            HIPCHECK(hipMemcpyAsync(C.d_todo, todo[k].data(), todo[k].size() * 4, hipMemcpyHostToDevice, cs));
+            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
             const RunParams *dp = h->d_params;
-            HIPCHECK(hipEventRecord(C.start, C.stream));
+            HIPCHECK(hipEventRecord(C.start, cs));
             C.nh += (long long)todo[k].size();
-            if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(256), 0, C.stream, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, C.stream, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(1024), 0, C.stream, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            HIPCHECK(hipEventRecord(C.done, C.stream));
+            if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(1024), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            HIPCHECK(hipEventRecord(C.done, cs));
             HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         }
         if (!any) break;

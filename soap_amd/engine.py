@@ -149,8 +149,11 @@ class Engine:
     def row_columns(self):
         return int(self._lib.soap_engine_row_columns(self._h))
 
-    def fetch(self):
+    def fetch(self, table=True):
+        """Copy status/radii/stats (and, unless table=False, the fp64 result table) to the host."""
         n, nc = self.n_halo, self.row_columns
+        if not table:
+            return self._fetch_small()
         table = np.zeros((n, nc), dtype=np.float64)
         status = np.zeros(n, dtype=np.int32)
         search = np.zeros(n, dtype=np.float64)
@@ -163,6 +166,20 @@ class Engine:
                 )
             )
         return dict(table=table, status=status, search_radius=search, read_radius=read, stats=stats)
+
+    def _fetch_small(self):
+        n = self.n_halo
+        status = np.zeros(n, dtype=np.int32)
+        search = np.zeros(n, dtype=np.float64)
+        read = np.zeros(n, dtype=np.float64)
+        stats = np.zeros((n, 4), dtype=np.int64)
+        if n > 0:
+            self._check(
+                self._lib.soap_engine_fetch(
+                    self._h, None, *[C.c_void_p(x.ctypes.data) for x in (status, search, read, stats)]
+                )
+            )
+        return dict(table=None, status=status, search_radius=search, read_radius=read, stats=stats)
 
     def copy_table_to(self, tensor):
         """Device-to-device copy of the result table into a torch CUDA float64 tensor."""
