@@ -11,7 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, List
 
-from .particle_selection import SO_properties, aperture_properties, subhalo_properties
+from .particle_selection import (SO_properties, aperture_properties, projected_aperture_properties,
+                                 subhalo_properties)  # fmt: skip
 
 # compute_halo_properties.py:249-262
 DEFAULT_SO_VARIATIONS = {
@@ -38,8 +39,13 @@ def aperture_variations(radii_kpc=(30.0, 50.0, 100.0)) -> Dict:
     return out
 
 
+def projected_variations(radii_kpc=(10.0, 30.0, 50.0, 100.0)) -> Dict:
+    """compute_halo_properties.py:442-450"""
+    return {f"{r:.0f}_kpc": {"radius_in_kpc": float(r)} for r in radii_kpc}
+
+
 def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture_vars=None,
-                         parameters=None, classes=None) -> List:  # fmt: skip
+                         parameters=None, classes=None, projected_vars=None) -> List:  # fmt: skip
     """`classes` lets the parity tests build the same list out of the oracle's classes."""
     if classes is None:
         classes = dict(
@@ -53,6 +59,8 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
                 cellgrid, parameters, r, None, None, None, None, category_filter, filt, radii),
             exclusive=lambda filt, r, radii: aperture_properties.ExclusiveSphereProperties(
                 cellgrid, parameters, r, None, None, None, None, category_filter, filt, radii),
+            projected=lambda filt, r, radii: projected_aperture_properties.ProjectedApertureProperties(
+                cellgrid, parameters, r, None, category_filter, filt, radii),
         )  # fmt: skip
     SO_variations = DEFAULT_SO_VARIATIONS if SO_variations is None else SO_variations
     aperture_vars = {} if aperture_vars is None else aperture_vars
@@ -78,4 +86,10 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
             halo_prop_list.append(classes["inclusive"](v.get("filter", "basic"), v["radius_in_kpc"], radii_kpc))
         else:
             halo_prop_list.append(classes["exclusive"](v.get("filter", "basic"), v["radius_in_kpc"], exclusive_radii_kpc))
+    # projected apertures sorted by radius (compute_halo_properties.py:451-489)
+    projected_vars = {} if projected_vars is None else projected_vars
+    projected_vars = dict(sorted(projected_vars.items(), key=lambda x: x[1].get("radius_in_kpc", 0)))
+    projected_radii_kpc = [v["radius_in_kpc"] for v in projected_vars.values()]
+    for v in projected_vars.values():
+        halo_prop_list.append(classes["projected"](v.get("filter", "basic"), v["radius_in_kpc"], projected_radii_kpc))
     return halo_prop_list

@@ -78,8 +78,8 @@ struct TypeDev {
 
 struct SlabDev {
     long long cap;
-    double *r, *m, *dx, *dy, *dz, *vx, *vy, *vz, *cum, *q, *dens;
-    unsigned *pidx;
+    double *r, *m, *dx, *dy, *dz, *vx, *vy, *vz, *cum, *q, *dens, *pr;
+    unsigned *pidx, *pi;
     unsigned char *flags;
 };
 
@@ -466,7 +466,7 @@ struct soap_engine {
 
 static void free_slab(soap_engine::Class &c) {
     void *ptrs[] = {c.slab.r, c.slab.m, c.slab.dx, c.slab.dy, c.slab.dz, c.slab.vx,
-                    c.slab.vy, c.slab.vz, c.slab.cum, c.slab.q, c.slab.dens, c.slab.pidx, c.slab.flags};
+                    c.slab.vy, c.slab.vz, c.slab.cum, c.slab.q, c.slab.dens, c.slab.pr, c.slab.pidx, c.slab.pi, c.slab.flags};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c.slab = SlabDev{};
     c.cap = 0;
@@ -478,9 +478,10 @@ static int alloc_slab(soap_engine::Class &c, long long cap, int groups) {
     free_slab(c);
     size_t ne = (size_t)cap * (size_t)groups;
     double **dp[] = {&c.slab.r, &c.slab.m, &c.slab.dx, &c.slab.dy, &c.slab.dz,
-                     &c.slab.vx, &c.slab.vy, &c.slab.vz, &c.slab.cum, &c.slab.q, &c.slab.dens};
+                     &c.slab.vx, &c.slab.vy, &c.slab.vz, &c.slab.cum, &c.slab.q, &c.slab.dens, &c.slab.pr};
     for (double **p : dp) HIPCHECK(hipMalloc((void **)p, ne * sizeof(double)));
     HIPCHECK(hipMalloc((void **)&c.slab.pidx, ne * sizeof(unsigned)));
+    HIPCHECK(hipMalloc((void **)&c.slab.pi, ne * sizeof(unsigned)));
     HIPCHECK(hipMalloc((void **)&c.slab.flags, ne));
     c.slab.cap = cap;
     c.cap = cap;
@@ -748,7 +749,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (p < 1 || p >= c || calcs[p].kind < SOAP_CALC_SO_DENSITY || calcs[p].kind > SOAP_CALC_SO_MULTIPLE)
                 return fail(-7, "SO radius multiple needs an earlier SO as parent (SO_properties.py:3912-3916)");
         }
-        if ((calcs[c].kind == SOAP_CALC_APERTURE_EXCL || calcs[c].kind == SOAP_CALC_APERTURE_INCL) && calcs[c].parent >= 0) {
+        if ((calcs[c].kind == SOAP_CALC_APERTURE_EXCL || calcs[c].kind == SOAP_CALC_APERTURE_INCL || calcs[c].kind == SOAP_CALC_PROJECTED) && calcs[c].parent >= 0) {
             int p = calcs[c].parent;
             if (p < 1 || p >= c || calcs[p].kind != calcs[c].kind) return fail(-8, "aperture parent must be an earlier aperture of the same kind");
         }

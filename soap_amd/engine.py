@@ -205,7 +205,7 @@ class Engine:
     def phase_cycles(self):
         out = (C.c_uint64 * 8)()
         self._check(self._lib.soap_engine_phase_cycles(self._h, out))
-        names = ("select", "sort", "materialize", "reduce", "scan", "_5", "total", "_7")
+        names = ("select", "sort", "materialize", "reduce", "scan", "so_search", "total", "misc")
         return {n: int(v) for n, v in zip(names, out) if not n.startswith("_")}
 
     def kernel_ms(self, name: str) -> float:

@@ -31,7 +31,7 @@ def oracle_filters(category_filter: CategoryFilter):
             for k, v in category_filter.filters.items()}  # fmt: skip
 
 
-def oracle_prop_list(sc, category_filter, SO_variations=None, aperture_vars=None):
+def oracle_prop_list(sc, category_filter, SO_variations=None, aperture_vars=None, projected_vars=None):
     u = oracle_units(sc)
     f = oracle_filters(category_filter)
     dmo = category_filter.dmo
@@ -44,15 +44,18 @@ def oracle_prop_list(sc, category_filter, SO_variations=None, aperture_vars=None
             u, r, True, radii, halo_filter=filt, filters=f, dmo=dmo),
         exclusive=lambda filt, r, radii: ho.ApertureProperties(
             u, r, False, radii, halo_filter=filt, filters=f, dmo=dmo),
+        projected=lambda filt, r, radii: ho.ProjectedApertureProperties(
+            u, r, radii, halo_filter=filt, filters=f, dmo=dmo),
     )  # fmt: skip
-    return u, chp.build_halo_prop_list(None, None, SO_variations, aperture_vars, classes=classes)
+    return u, chp.build_halo_prop_list(None, None, SO_variations, aperture_vars, classes=classes,
+                                       projected_vars=projected_vars)
 
 
 def run_oracle(sc, data_np, halos_np, category_filter, SO_variations=None, aperture_vars=None,
-               resolution=None, rows=None):  # fmt: skip
+               resolution=None, rows=None, projected_vars=None):  # fmt: skip
     """Oracle end to end on a NumPy chunk.  Returns (results dict row -> halo_result, stats,
     halo_arrays after the pass)."""
-    u, props = oracle_prop_list(sc, category_filter, SO_variations, aperture_vars)
+    u, props = oracle_prop_list(sc, category_filter, SO_variations, aperture_vars, projected_vars)
     data = {pt: d for pt, d in data_np.items()}
     mesh = {}
     for pt, d in data.items():

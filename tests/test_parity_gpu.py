@@ -56,7 +56,7 @@ def compare_halo(o, hr, sc, rtol=1e-10):
         R = sc.boxsize  # generous length scale for com offsets
         scale = {
             "Ldm": M * 2.0 * vscale, "veldisp_matrix_dm": vscale**2, "vcom": vscale,
-            "com": 1.0,
+            "com": 1.0, "proj_veldisp_dm": vscale,
         }.get(key, 0.0)  # fmt: skip
         helpers.assert_close(okey, got, want, rtol=rtol, scale=scale, atol_factor=1e-12)
     return nchecked
@@ -208,4 +208,28 @@ def test_stored_dtypes_follow_the_property_table(built_library):
             stored = val[0]
             assert stored.dtype == prop.dtype and stored.shape == (prop.shape,)
             assert val[2] == prop.output_physical
+    engine.close()
+
+
+def test_projected_apertures_match_oracle(built_library):
+    """ProjectedAperture/{10,30,50,100}kpc/proj{x,y,z}: bound particles inside a 2D radius
+    (projected_aperture_properties.py:98-198), incl. the copy rule for apertures beyond the
+    enclose radius (:1827-1884)."""
+    sc, data, halos = make_chunk(150000, 120, seed=21, satellite_fraction=0.2)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}}
+    pj_vars = chp.projected_variations((10.0, 30.0, 100.0, 1000.0, 3000.0))
+    props = chp.build_halo_prop_list(sc, cf, so_vars, chp.aperture_variations((50.0,)), projected_vars=pj_vars)
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, chp.aperture_variations((50.0,)),
+                                            projected_vars=pj_vars)  # fmt: skip
+    assert np.array_equal(ha["done"], ha_ref["done"])
+    ncopy = 0
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        compare_halo(ref[row], results[j], sc)
+        a = helpers.engine_value(results[j], "ProjectedAperture/1000kpc/projx", "Mtot")
+        b = helpers.engine_value(results[j], "ProjectedAperture/3000kpc/projx", "Mtot")
+        ncopy += int(a[0] == b[0] and a[0] > 0)
+    assert ncopy > 0
     engine.close()
