@@ -233,3 +233,39 @@ def test_projected_apertures_match_oracle(built_library):
         ncopy += int(a[0] == b[0] and a[0] > 0)
     assert ncopy > 0
     engine.close()
+
+
+def test_hydro_chunk_matches_oracle(built_library):
+    """Four particle types (gas, DM, stars, BHs) with unequal masses: type-major concatenation of
+    the reference (SO_properties.py:3520-3550) only shows up as summation order; counts and masses
+    per type, the sequential cumulative profile (unequal masses!) and the SO radii must agree."""
+    sc, data, halos = make_chunk(160000, 100, seed=33, hydro=True)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=False)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "500_crit": {"value": 500.0, "type": "crit"},
+               "BN98": {"value": 0.0, "type": "BN98"}}  # fmt: skip
+    ap_vars = chp.aperture_variations((30.0, 100.0))
+    pj_vars = chp.projected_variations((30.0, 100.0))
+    props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars)
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, ap_vars, projected_vars=pj_vars)
+    assert np.array_equal(ha["done"], ha_ref["done"])
+    nchecked = 0
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        o, hr = ref[row], results[j]
+        for okey, val in o.items():
+            group, key = okey.rsplit("/", 1)
+            got = helpers.engine_value(hr, group, key)
+            want = val.raw
+            nchecked += 1
+            if key in ("Ndm", "Ngas", "Nstar", "Nbh"):
+                assert np.array_equal(got, want), f"{okey}: {got} != {want}"
+            else:
+                M, vscale = _scales(o, group)
+                scale = {"Ldm": M * 2.0 * vscale, "veldisp_matrix_dm": vscale**2, "vcom": vscale, "com": 1.0,
+                         "proj_veldisp_dm": vscale}.get(key, 0.0)  # fmt: skip
+                helpers.assert_close(okey, got, want, rtol=1e-10, scale=scale, atol_factor=1e-12)
+    assert nchecked > 5000
+    ngas = sum(int(helpers.engine_value(r, "BoundSubhalo", "Ngas")[0]) for r in results)
+    assert ngas > 0
+    engine.close()
