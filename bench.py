@@ -41,6 +41,10 @@ WORKLOADS = {
                name="synthetic DMO 1e8 particles / 1e5 halos, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc"),
     "c2": dict(n_part=10_000_000, n_halo=10_000, so="200_crit", apertures=(),
                name="synthetic DMO 1e7 particles / 1e4 halos, BoundSubhalo + SO_200_crit"),
+    "c5": dict(n_part=25_000_000, n_halo=25_000, so="default", apertures=(30.0, 50.0, 100.0),
+               projected=(10.0, 30.0, 50.0, 100.0), hydro=True,
+               name="synthetic hydro (gas+DM+stars+BH) 2.5e7 particles / 2.5e4 halos per GPU (2e8 on 8 GPUs), "
+                    "BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc + projected 10/30/50/100 kpc"),
     "tiny": dict(n_part=400_000, n_halo=400, so="default", apertures=(30.0, 50.0, 100.0),
                  name="synthetic DMO 4e5 particles / 4e2 halos (plumbing check)"),
 }  # fmt: skip
@@ -50,10 +54,11 @@ def build_props(sc, wl):
     from soap_amd import compute_halo_properties as chp
     from soap_amd.core.category_filter import CategoryFilter
 
-    cf = CategoryFilter(dmo=True)
+    cf = CategoryFilter(dmo=not wl.get("hydro", False))
     so_vars = None if wl["so"] == "default" else {"200_crit": {"value": 200.0, "type": "crit"}}
     ap_vars = chp.aperture_variations(wl["apertures"]) if wl["apertures"] else {}
-    return cf, so_vars, ap_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars)
+    pj_vars = chp.projected_variations(wl["projected"]) if wl.get("projected") else {}
+    return cf, so_vars, ap_vars, pj_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars)
 
 
 def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
@@ -67,8 +72,7 @@ def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
     from oracle import halo_oracle as ho
 
     L = sc.boxsize
-    pos = data[1]["Coordinates"]
-    n = pos.shape[0]
+    n = sum(int(d["Coordinates"].shape[0]) for d in data.values())
     frac = min(1.0, (1.5e6 / n) ** (1.0 / 3.0))
     side = L * frac
     rr = halos["read_radius"]
@@ -77,14 +81,18 @@ def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
     rows = torch.nonzero(inside).flatten()
     if rows.numel() == 0:
         return None
-    psel = (pos <= side).all(dim=1)
-    d_np = {1: {k: v[psel].cpu().numpy() for k, v in data[1].items()}}
+    d_np = {}
+    for pt, d in data.items():
+        psel = (d["Coordinates"] <= side).all(dim=1)
+        d_np[pt] = {k: v[psel].cpu().numpy() for k, v in d.items()}
     h_np = {k: v[rows].cpu().numpy() for k, v in halos.items()}
-    cf, so_vars, ap_vars, _ = build_props(sc, wl)
-    u, props = helpers.oracle_prop_list(sc, cf, so_vars, ap_vars)
-    npart = d_np[1]["Masses"].shape[0]
-    res = max(1, int(round(ho.mesh_resolution(n) * frac)))
-    mesh = {1: ho.Mesh(d_np[1]["Coordinates"], res)}
+    cf, so_vars, ap_vars, pj_vars, _ = build_props(sc, wl)
+    u, props = helpers.oracle_prop_list(sc, cf, so_vars, ap_vars, pj_vars)
+    npart = sum(d["Masses"].shape[0] for d in d_np.values())
+    mesh = {}
+    for pt, d in d_np.items():
+        n_pt = int(data[pt]["Coordinates"].shape[0])
+        mesh[pt] = ho.Mesh(d["Coordinates"], max(1, int(round(ho.mesh_resolution(n_pt) * frac))))
     A = len(props)
     td = ho.target_density_of(props, u)
     t0 = time.perf_counter()
@@ -140,10 +148,11 @@ def main():
 
     wl = WORKLOADS[args.workload]
     t_gen = time.time()
-    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed + rank, device=f"cuda:{local_rank}")
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed + rank, device=f"cuda:{local_rank}",
+                                 hydro=wl.get("hydro", False))
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
-    cf, so_vars, ap_vars, props = build_props(sc, wl)
+    cf, so_vars, ap_vars, pj_vars, props = build_props(sc, wl)
     A = len(props)
     halos_np = {k: v.cpu().numpy() for k, v in halos.items()}
     H = len(halos_np["index"])

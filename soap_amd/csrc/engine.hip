@@ -116,15 +116,45 @@ struct RunParams {
 // ------------------------------------------------------------------------------------------
 // wave / block primitives
 // ------------------------------------------------------------------------------------------
+// Cross-lane primitives on DPP (data-parallel primitives: VALU-rate lane moves inside rows of 16 lanes,
+// row broadcasts across rows).  HIP's __shfl_* lower to ds_bpermute, i.e. a round trip through the LDS
+// crossbar per 32-bit half and step -- rocprof showed the halo kernels latency-bound with most LDS
+// instructions being exactly those shuffles.
+template <int CTRL, int ROW_MASK = 0xf>
+SOAP_DEV double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+SOAP_DEV double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, same value returned to every lane (fixed association)
 SOAP_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);        // every lane of a 16-lane row holds the row sum
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 SOAP_DEV double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 SOAP_DEV long long wave_min_ll(long long v) {
 #pragma unroll
@@ -134,13 +164,15 @@ SOAP_DEV long long wave_min_ll(long long v) {
     }
     return v;
 }
-// inclusive scan inside a wave
+// inclusive scan inside a wave (row_shr with zero fill inside rows of 16, then row broadcasts)
 SOAP_DEV double wave_scan(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
+    (void)lane;
+    v += dpp_f64<DPP_ROW_SHR(1)>(v);
+    v += dpp_f64<DPP_ROW_SHR(2)>(v);
+    v += dpp_f64<DPP_ROW_SHR(4)>(v);
+    v += dpp_f64<DPP_ROW_SHR(8)>(v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);   // last lane of rows 0 and 2 into rows 1 and 3
+    v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // lane 31 into rows 2 and 3
     return v;
 }
 
@@ -322,7 +354,7 @@ enum {
 #define GRP 64
 #define GNW 1
 #define GWG 64
-#define GCH 1024
+#define GCH 512
 #define GLB 4
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 namespace g64 {
@@ -339,7 +371,7 @@ namespace g64 {
 #define GNW 4
 #define GWG 256
 #define GCH 4096
-#define GLB 4
+#define GLB 3
 #define GSYNC() __syncthreads()
 namespace g256 {
 #include "halo_kernel.inc"
@@ -808,7 +840,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // A halo whose search sphere outgrows its class' slab is retried in the next class.
     const long long nb_small = 256, nb_medium = 16384;
     long long caps[3] = {1ll << 15, 1ll << 18, 1ll << 20};
-    int groups[3] = {2816, 768, 128};
+    int groups[3] = {4096, 768, 128};
     if (h->cfg.slab_capacity > 0) {
         long long c0 = next_pow2(h->cfg.slab_capacity);
         caps[0] = c0; caps[1] = c0 * 8; caps[2] = c0 * 64;
