@@ -103,6 +103,7 @@ struct RunParams {
     double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
     int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
     double first_factor;   // first sorted superset reaches first_factor * search_radius
+    int debug_stop;        // diagnostics: leave the per-halo code after stage N (env SOAP_ENGINE_DEBUG_STOP)
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -348,14 +349,16 @@ enum {
     A_RMAX = 37                        // max r  (max-reduction)
 };
 
+#define GAS __attribute__((address_space(1)))
+
 // ---- three instantiations of the per-halo code (halo_kernel.inc) ---------------------------------
 // a wavefront-level "barrier": LDS and global accesses of one wave are issued in order, so only the
 // compiler and outstanding memory operations have to be fenced
 #define GRP 64
 #define GNW 1
 #define GWG 64
-#define GCH 512
-#define GLB 4
+#define GCH 1024
+#define GLB 2
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 namespace g64 {
 #include "halo_kernel.inc"
@@ -371,7 +374,7 @@ namespace g64 {
 #define GNW 4
 #define GWG 256
 #define GCH 4096
-#define GLB 3
+#define GLB 2
 #define GSYNC() __syncthreads()
 namespace g256 {
 #include "halo_kernel.inc"
@@ -398,6 +401,57 @@ namespace g1024 {
 #undef GCH
 #undef GLB
 #undef GSYNC
+
+// Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
+// (an upper bound of what the halo kernel will have to sort).  Used to pick the thread-group class of
+// each halo and to start the heaviest halos first: bound-particle counts alone miss small halos that sit
+// next to a giant (their search sphere swallows the giant's cells).
+__global__ void k_estimate(const RunParams *Pp, long long *est) {
+    const RunParams &P = *Pp;
+    long long h = blockIdx.x * (long long)BLK + threadIdx.x;
+    if (h >= P.halo.n) return;
+    double R = fmin(P.halo.read_radius[h], P.halo.search_radius[h] * P.first_factor);
+    long long tot = 0;
+    for (int ts = 0; ts < SOAP_NTYPES; ts++) {
+        const TypeDev &T = P.t[ts];
+        if (T.n == 0) continue;
+        unsigned long long mk[3][4];
+        for (int d = 0; d < 3; d++) {
+            for (int k = 0; k < 4; k++) mk[d][k] = 0;
+            double c = P.halo.cofp[3 * h + d], L = P.boxsize;
+            int min_copy = 0, max_copy = 0, guard = 0;
+            while (c + (double)(min_copy - 1) * L + R >= T.pos_min[d] && guard++ < 64) min_copy--;
+            guard = 0;
+            while (c + (double)(max_copy + 1) * L - R <= T.pos_max[d] && guard++ < 64) max_copy++;
+            for (int cp = min_copy; cp <= max_copy; cp++) {
+                double lo = fmax(T.pos_min[d], c + (double)cp * L - R);
+                double hi = fmin(T.pos_max[d], c + (double)cp * L + R);
+                double qlo = floor((lo - T.pos_min[d]) / T.cell_size[d]);
+                double qhi = floor((hi - T.pos_min[d]) / T.cell_size[d]);
+                int ilo = qlo < 0.0 ? 0 : (qlo > 1e9 ? 1000000000 : (int)qlo);
+                int ihi = qhi < -1.0 ? -1 : (qhi > (double)(T.res - 1) ? T.res - 1 : (int)qhi);
+                for (int q = ilo; q <= ihi; q++) mk[d][q >> 6] |= 1ull << (q & 63);
+            }
+        }
+        const int res = T.res;
+        for (int k = 0; k < res; k++) {
+            if (!((mk[2][k >> 6] >> (k & 63)) & 1ull)) continue;
+            for (int j = 0; j < res; j++) {
+                if (!((mk[1][j >> 6] >> (j & 63)) & 1ull)) continue;
+                long long rowbase = (long long)res * j + (long long)res * res * k;
+                int i0 = 0;
+                while (i0 < res) {
+                    if (!((mk[0][i0 >> 6] >> (i0 & 63)) & 1ull)) { i0++; continue; }
+                    int i1 = i0;
+                    while (i1 + 1 < res && ((mk[0][(i1 + 1) >> 6] >> ((i1 + 1) & 63)) & 1ull)) i1++;
+                    tot += (long long)(T.cell_offset[rowbase + i1 + 1] - T.cell_offset[rowbase + i0]);
+                    i0 = i1 + 1;
+                }
+            }
+        }
+    }
+    est[h] = tot;
+}
 
 // brute-force membership list for verification (same arithmetic as the property kernels)
 __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double L, double R,
@@ -829,6 +883,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (calcs[c].kind == SOAP_CALC_SO_DENSITY) P.first_factor = std::max(P.first_factor, 2.0736);
         if (calcs[c].kind == SOAP_CALC_SO_MULTIPLE) P.first_factor = std::max(P.first_factor, 0.86 * calcs[c].radius);
     }
+    { const char *e = getenv("SOAP_ENGINE_DEBUG_STOP"); P.debug_stop = e ? atoi(e) : 0; }
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
@@ -836,22 +891,38 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipMemsetAsync(h->d_phase, 0, 8 * sizeof(unsigned long long), st));
     HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
 
-    // three classes of halos by bound-particle count: one wavefront, 256 threads, 1024 threads per halo.
-    // A halo whose search sphere outgrows its class' slab is retried in the next class.
-    const long long nb_small = 256, nb_medium = 16384;
+    // three classes of halos by estimated sphere content: one wavefront, 256 threads, 1024 threads per
+    // halo.  A halo whose search sphere outgrows its class' slab is retried in the next class.
+    long long nb_small = 8192, nb_medium = 131072;
+    { const char *e = getenv("SOAP_ENGINE_NB_SMALL"); if (e) nb_small = atoll(e); }
+    { const char *e = getenv("SOAP_ENGINE_NB_MEDIUM"); if (e) nb_medium = atoll(e); }
     long long caps[3] = {1ll << 15, 1ll << 18, 1ll << 20};
-    int groups[3] = {4096, 768, 128};
+    int groups[3] = {2048, 512, 128};
     if (h->cfg.slab_capacity > 0) {
         long long c0 = next_pow2(h->cfg.slab_capacity);
         caps[0] = c0; caps[1] = c0 * 8; caps[2] = c0 * 64;
+        nb_small = c0 / 4; nb_medium = c0 * 2;
     }
     if (h->cfg.n_workgroups > 0) { groups[0] = h->cfg.n_workgroups * 4; groups[1] = h->cfg.n_workgroups; groups[2] = std::max(1, h->cfg.n_workgroups / 4); }
     for (int k = 0; k < 3; k++) caps[k] = std::min(caps[k], cap_max);
+    std::vector<long long> est(h->n_halo);
+    {
+        long long *d_est;
+        HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
+        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK - 1) / BLK)), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est);
+        HIPCHECK(hipMemcpyAsync(est.data(), d_est, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        h->pool.release(d_est, (size_t)h->n_halo * 8);
+    }
     std::vector<int> todo[3];
     for (long long i = 0; i < h->n_halo; i++) {
-        long long nb = h->h_nrbound[i];
+        long long nb = est[i];
         todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
     }
+    // heaviest first inside every class (the reference orders by bound-particle count for the same
+    // reason, chunk_tasks.py:118-120); ties keep the staged order
+    for (int k = 0; k < 3; k++)
+        std::stable_sort(todo[k].begin(), todo[k].end(), [&](int a, int b) { return est[a] > est[b]; });
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
