@@ -183,9 +183,10 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t type_slot, d
 double soap_engine_kernel_ms(const soap_engine *h, const char *name);
 
 /* diagnostic: shader cycles (summed over workgroups, thread 0's clock) the last run spent in
- * each phase of the halo kernel: [0] select, [1] sort, [2] materialize+cumsum, [3] moment
- * reductions, [4] scans, [5] reserved, [6] whole halo, [7] reserved */
-int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out8);
+ * each phase of the halo kernel (32 slots): [0] select, [1] sort, [2] materialize+cumsum, [3] moment
+ * reductions, [4] scans, [5] SO radius search, [6] whole halo, [7] other; [8..31] sub-phases of those
+ * (names in soap_amd/engine.py::PHASE_NAMES) */
+int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out32);
 
 #ifdef __cplusplus
 }

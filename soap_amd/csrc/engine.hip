@@ -103,13 +103,13 @@ struct RunParams {
     double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
     int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
     double first_factor;   // first sorted superset reaches first_factor * search_radius
-    int debug_stop;        // diagnostics: leave the per-halo code after stage N (env SOAP_ENGINE_DEBUG_STOP)
+    int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
     double *table;
     unsigned *queue;
-    unsigned long long *phase;   // [8] accumulated s_memtime cycles of thread 0 per phase
+    unsigned long long *phase;   // [32] accumulated s_memtime cycles of thread 0 per phase
     const soap_calc_desc *calcs;  // device copy
     const int *coloff;            // device: column offset per calc
 };
@@ -208,6 +208,30 @@ __global__ void k_minmax(const double *pos, long long n, double *partial /*[grid
     }
 }
 
+// counter[key] += 1 for every active lane, returning the value each lane would have got from its own
+// atomicAdd.  Snapshot particles arrive spatially coherent (halo by halo / cell by cell), so most lanes
+// of a wavefront hit the same counter: lanes with equal keys are merged into one atomic (up to 4 distinct
+// keys per wavefront; whatever is left falls back to one atomic per lane).
+__device__ __forceinline__ unsigned wave_agg_inc(unsigned *counter, unsigned key, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    unsigned res = 0;
+    bool mine = active;
+    for (int round = 0; round < 4 && todo; round++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned k0 = __shfl(key, leader, 64);
+        const bool in = mine && key == k0;
+        const unsigned long long grp = __ballot(in);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&counter[k0], (unsigned)__popcll(grp));
+        base = __shfl(base, leader, 64);
+        if (in) { res = base + (unsigned)__popcll(grp & ((1ull << lane) - 1ull)); mine = false; }
+        todo &= ~grp;
+    }
+    if (mine) res = atomicAdd(&counter[key], 1u);
+    return res;
+}
+
 struct MeshGeom {
     double pos_min[3], cell_size[3];
     int res;
@@ -230,7 +254,7 @@ __global__ void k_cellid(const double *pos, long long n, MeshGeom g, unsigned *c
         unsigned id = (unsigned)c[0] + (unsigned)g.res * (unsigned)c[1] +
                       (unsigned)g.res * (unsigned)g.res * (unsigned)c[2];
         cell[i] = id;
-        atomicAdd(&count[id], 1u);
+        (void)wave_agg_inc(count, id, true);
     }
 }
 
@@ -301,7 +325,7 @@ __global__ void k_scatter(const unsigned *cell, long long n, const unsigned *off
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
          i += (long long)gridDim.x * BLK) {
         unsigned c = cell[i];
-        unsigned r = atomicAdd(&cursor[c], 1u);
+        unsigned r = wave_agg_inc(cursor, c, true);
         sort_idx[offset[c] + r] = (unsigned)i;
     }
 }
@@ -515,6 +539,7 @@ struct TypeHost {
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
+    bool own_streams = false;   // one priority stream per class
     DevPool pool;
     TypeHost t[SOAP_NTYPES];
     // halos
@@ -530,7 +555,7 @@ struct soap_engine {
     unsigned *d_queue = nullptr;
     RunParams *d_params = nullptr;
     unsigned long long *d_phase = nullptr;
-    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long phase[32] = {};
     // per-class slabs/queues: class 0 = one wavefront per halo, 1 = 256 threads, 2 = 1024 threads
     struct Class {
         long long cap = 0;
@@ -613,14 +638,25 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
     HIPCHECK(hipEventCreate(&h->ev0));
     HIPCHECK(hipEventCreate(&h->ev1));
     HIPCHECK(hipMalloc((void **)&h->d_queue, sizeof(unsigned)));
+    // one stream per thread-group class, on distinct priority levels where the device offers three:
+    // streams of equal priority may be mapped onto the same hardware queue (and then serialise), streams of
+    // different priority are not.  Giants (class 2) first: they are the tail.
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    h->own_streams = (prio_least - prio_greatest >= 2) && !getenv("SOAP_ENGINE_TWO_STREAMS");
     for (int k = 0; k < 3; k++) {
-        HIPCHECK(hipStreamCreate(&h->cls[k].stream));
+        if (h->own_streams) {
+            int prio = k == 0 ? prio_least : (k == 1 ? prio_least - 1 : prio_greatest);
+            HIPCHECK(hipStreamCreateWithPriority(&h->cls[k].stream, hipStreamNonBlocking, prio));
+        } else {
+            HIPCHECK(hipStreamCreate(&h->cls[k].stream));
+        }
         HIPCHECK(hipEventCreate(&h->cls[k].done));
         HIPCHECK(hipEventCreate(&h->cls[k].start));
         HIPCHECK(hipMalloc((void **)&h->cls[k].d_queue, sizeof(unsigned)));
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
-    HIPCHECK(hipMalloc((void **)&h->d_phase, 8 * sizeof(unsigned long long)));
+    HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
     *out = h;
     return 0;
 }
@@ -883,12 +919,12 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (calcs[c].kind == SOAP_CALC_SO_DENSITY) P.first_factor = std::max(P.first_factor, 2.0736);
         if (calcs[c].kind == SOAP_CALC_SO_MULTIPLE) P.first_factor = std::max(P.first_factor, 0.86 * calcs[c].radius);
     }
-    { const char *e = getenv("SOAP_ENGINE_DEBUG_STOP"); P.debug_stop = e ? atoi(e) : 0; }
+    { const char *e = getenv("SOAP_ENGINE_PROFILE"); P.profile = e ? atoi(e) : 0; }
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
     P.phase = h->d_phase;
-    HIPCHECK(hipMemsetAsync(h->d_phase, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHECK(hipMemsetAsync(h->d_phase, 0, 32 * sizeof(unsigned long long), st));
     HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
 
     // three classes of halos by estimated sphere content: one wavefront, 256 threads, 1024 threads per
@@ -923,21 +959,24 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // reason, chunk_tasks.py:118-120); ties keep the staged order
     for (int k = 0; k < 3; k++)
         std::stable_sort(todo[k].begin(), todo[k].end(), [&](int a, int b) { return est[a] > est[b]; });
+    int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
+    { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
-        // launch order: the 1024-thread class (few, long halos) on its own stream; the 256-thread class and
-        // the wavefront class share a second stream (ROCm maps streams onto few hardware queues: two
-        // user streams get distinct queues, three do not)
-        const int order[3] = {2, 1, 0};   // submission order; classes 2 and 0 share a stream
+        // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
+        // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
+        // (two equal-priority user streams get distinct hardware queues, three do not).
+        const int order[3] = {2, 1, 0};
         for (int oi = 0; oi < 3; oi++) {
             const int k = order[oi];
             soap_engine::Class &C = h->cls[k];
-            hipStream_t cs = (k == 1) ? h->cls[0].stream : h->cls[2].stream;   // 1024-thread class, then wavefront class | 256-thread class
+            hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
             if (todo[k].empty()) continue;
+            if (only_class >= 0 && k != only_class) { todo[k].clear(); continue; }   // diagnostics
             any = true;
             int ng = (int)std::min<long long>(groups[k], (long long)todo[k].size());
             int nwg = ng;
@@ -989,7 +1028,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (int k = 0; k < 3; k++) todo[k].swap(next[k]);
     }
     h->ms_halo = ms_total;
-    HIPCHECK(hipMemcpy(h->phase, h->d_phase, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(h->phase, h->d_phase, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1060,9 +1099,9 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t ts, double r
     return (int64_t)cnt;
 }
 
-int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out8) {
-    if (!h || !out8) return fail(-1, "null argument");
-    for (int i = 0; i < 8; i++) out8[i] = h->phase[i];
+int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out32) {
+    if (!h || !out32) return fail(-1, "null argument");
+    for (int i = 0; i < 32; i++) out32[i] = h->phase[i];
     return 0;
 }
 

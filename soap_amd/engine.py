@@ -26,6 +26,13 @@ PTYPE_OF_SLOT = (0, 1, 4, 5)
 SLOT_OF_PTYPE = {0: 0, 1: 1, 4: 2, 5: 3}
 
 
+# slots of soap_engine_phase_cycles; entries from index 8 on are sub-phases (nested inside the first eight)
+PHASE_NAMES = ("select", "sort", "materialize", "reduce", "scan", "so_search", "total", "misc",
+               "reduce_xlane", "finalize_moments", "finalize_scan", "scan_argmax", "mat_cumsum", "so_thread0",
+               "family_order", "stage_a", "prologue", "epilogue", "subhalo_spin", "projected",
+               "stage_b", "scan_setup") + ("",) * 10  # fmt: skip
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -203,10 +210,9 @@ class Engine:
         return out[:n].copy()
 
     def phase_cycles(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 32)()
         self._check(self._lib.soap_engine_phase_cycles(self._h, out))
-        names = ("select", "sort", "materialize", "reduce", "scan", "so_search", "total", "misc")
-        return {n: int(v) for n, v in zip(names, out) if not n.startswith("_")}
+        return {n: int(v) for n, v in zip(PHASE_NAMES, out) if n}
 
     def kernel_ms(self, name: str) -> float:
         return float(self._lib.soap_engine_kernel_ms(self._h, name.encode()))
