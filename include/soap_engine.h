@@ -155,7 +155,8 @@ int64_t soap_engine_row_columns(const soap_engine *h);
  *   table          [n_halo][row_columns] fp64 pre-cast values (zeros where not computed)
  *   status         [n_halo]
  *   search_radius, read_radius  [n_halo] updated radii (halo_tasks.py:393-402)
- *   stats          [n_halo][4] int64: n_loop, n_sel (final sphere), n_cand (final), reserved
+ *   stats          [n_halo][4] int64: n_loop, n_sel (final sphere), n_cand (final),
+ *                  shader clocks spent on the halo
  */
 int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double *search_radius,
                           double *read_radius, int64_t *stats);

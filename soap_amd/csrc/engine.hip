@@ -22,6 +22,8 @@
 //     sorted slab (wavefront shuffles, LDS across the 4 waves).
 //   * no MFMA anywhere: the path is bandwidth/latency bound fp64 vector work.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <functional>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -382,6 +384,7 @@ enum {
 #define GNW 1
 #define GWG 64
 #define GCH 1024
+#define SORT_NBMAX 64
 #define GLB 2
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 namespace g64 {
@@ -391,6 +394,7 @@ namespace g64 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef SORT_NBMAX
 #undef GLB
 #undef GSYNC
 
@@ -398,6 +402,7 @@ namespace g64 {
 #define GNW 4
 #define GWG 256
 #define GCH 4096
+#define SORT_NBMAX 256
 #define GLB 2
 #define GSYNC() __syncthreads()
 namespace g256 {
@@ -407,14 +412,19 @@ namespace g256 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef SORT_NBMAX
 #undef GLB
 #undef GSYNC
 
-#define GRP 1024
-#define GNW 16
-#define GWG 1024
+#ifndef G3T
+#define G3T 1024   // threads of the largest class (512 threads x 256 VGPRs measured slower: 35 vs 29 ms on C3)
+#endif
+#define GRP G3T
+#define GNW (G3T / 64)
+#define GWG G3T
 #define GCH 8192
-#define GLB 4
+#define SORT_NBMAX 512
+#define GLB (G3T == 1024 ? 4 : 2)
 #define GSYNC() __syncthreads()
 namespace g1024 {
 #include "halo_kernel.inc"
@@ -423,6 +433,7 @@ namespace g1024 {
 #undef GNW
 #undef GWG
 #undef GCH
+#undef SORT_NBMAX
 #undef GLB
 #undef GSYNC
 
@@ -430,18 +441,40 @@ namespace g1024 {
 // (an upper bound of what the halo kernel will have to sort).  Used to pick the thread-group class of
 // each halo and to start the heaviest halos first: bound-particle counts alone miss small halos that sit
 // next to a giant (their search sphere swallows the giant's cells).
+struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexed private array)
+    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    __device__ __forceinline__ void set_range(int lo, int hi) {   // bits [lo, hi]
+        for (int k = 0; k < 4; k++) {
+            int a = lo - 64 * k, b = hi - 64 * k;
+            a = a < 0 ? 0 : a;
+            b = b > 63 ? 63 : b;
+            if (a > b) continue;
+            unsigned long long m = (b - a == 63) ? ~0ull : (((1ull << (b - a + 1)) - 1ull) << a);
+            if (k == 0) w0 |= m; else if (k == 1) w1 |= m; else if (k == 2) w2 |= m; else w3 |= m;
+        }
+    }
+    __device__ __forceinline__ bool get(int q) const {
+        const int k = q >> 6;
+        const unsigned long long w = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+        return (w >> (q & 63)) & 1ull;
+    }
+};
+
+// one wavefront per halo: the lanes share the (k, j) mesh rows of the sphere's bounding cells, so the
+// dependent cell_offset lookups of one halo are in flight together
 __global__ void k_estimate(const RunParams *Pp, long long *est) {
     const RunParams &P = *Pp;
-    long long h = blockIdx.x * (long long)BLK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    long long h = blockIdx.x * (long long)(BLK / 64) + (threadIdx.x >> 6);
     if (h >= P.halo.n) return;
     double R = fmin(P.halo.read_radius[h], P.halo.search_radius[h] * P.first_factor);
     long long tot = 0;
     for (int ts = 0; ts < SOAP_NTYPES; ts++) {
         const TypeDev &T = P.t[ts];
         if (T.n == 0) continue;
-        unsigned long long mk[3][4];
+        Mask256 mk[3];
+#pragma unroll
         for (int d = 0; d < 3; d++) {
-            for (int k = 0; k < 4; k++) mk[d][k] = 0;
             double c = P.halo.cofp[3 * h + d], L = P.boxsize;
             int min_copy = 0, max_copy = 0, guard = 0;
             while (c + (double)(min_copy - 1) * L + R >= T.pos_min[d] && guard++ < 64) min_copy--;
@@ -454,27 +487,36 @@ __global__ void k_estimate(const RunParams *Pp, long long *est) {
                 double qhi = floor((hi - T.pos_min[d]) / T.cell_size[d]);
                 int ilo = qlo < 0.0 ? 0 : (qlo > 1e9 ? 1000000000 : (int)qlo);
                 int ihi = qhi < -1.0 ? -1 : (qhi > (double)(T.res - 1) ? T.res - 1 : (int)qhi);
-                for (int q = ilo; q <= ihi; q++) mk[d][q >> 6] |= 1ull << (q & 63);
+                if (ilo <= ihi) mk[d].set_range(ilo, ihi);
             }
         }
         const int res = T.res;
-        for (int k = 0; k < res; k++) {
-            if (!((mk[2][k >> 6] >> (k & 63)) & 1ull)) continue;
-            for (int j = 0; j < res; j++) {
-                if (!((mk[1][j >> 6] >> (j & 63)) & 1ull)) continue;
-                long long rowbase = (long long)res * j + (long long)res * res * k;
-                int i0 = 0;
-                while (i0 < res) {
-                    if (!((mk[0][i0 >> 6] >> (i0 & 63)) & 1ull)) { i0++; continue; }
-                    int i1 = i0;
-                    while (i1 + 1 < res && ((mk[0][(i1 + 1) >> 6] >> ((i1 + 1) & 63)) & 1ull)) i1++;
-                    tot += (long long)(T.cell_offset[rowbase + i1 + 1] - T.cell_offset[rowbase + i0]);
-                    i0 = i1 + 1;
-                }
-            }
+        // runs of set bits along x (a sphere gives at most a few: one per periodic copy)
+        int run_lo[4], run_hi[4], nrun = 0;
+        for (int i0 = 0; i0 < res && nrun < 4;) {
+            if (!mk[0].get(i0)) { i0++; continue; }
+            int i1 = i0;
+            while (i1 + 1 < res && mk[0].get(i1 + 1)) i1++;
+            run_lo[nrun] = i0; run_hi[nrun] = i1; nrun++;
+            i0 = i1 + 1;
+        }
+        const int nk = __popcll(mk[2].w0) + __popcll(mk[2].w1) + __popcll(mk[2].w2) + __popcll(mk[2].w3);
+        const int nj = __popcll(mk[1].w0) + __popcll(mk[1].w1) + __popcll(mk[1].w2) + __popcll(mk[1].w3);
+        for (int pair = lane; pair < nk * nj; pair += 64) {
+            const int ak = pair / nj, aj = pair - ak * nj;
+            // ak-th set bit of the z mask, aj-th set bit of the y mask
+            int k = -1, j = -1, seen = 0;
+            for (int q = 0; q < res; q++) if (mk[2].get(q)) { if (seen == ak) { k = q; break; } seen++; }
+            seen = 0;
+            for (int q = 0; q < res; q++) if (mk[1].get(q)) { if (seen == aj) { j = q; break; } seen++; }
+            const long long rowbase = (long long)res * j + (long long)res * res * k;
+            for (int r = 0; r < nrun; r++)
+                tot += (long long)(T.cell_offset[rowbase + run_hi[r] + 1] - T.cell_offset[rowbase + run_lo[r]]);
         }
     }
-    est[h] = tot;
+    // wave total
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if (lane == 0) est[h] = tot;
 }
 
 // brute-force membership list for verification (same arithmetic as the property kernels)
@@ -552,6 +594,8 @@ struct soap_engine {
     double *d_table = nullptr;
     soap_calc_desc *d_calcs = nullptr;
     int *d_coloff = nullptr;
+    size_t table_bytes = 0, calcs_bytes = 0, coloff_bytes = 0;
+    double ms_host_pre = 0, ms_host_setup = 0, ms_host_classify = 0, ms_host_total = 0;   // wall clock inside run()
     unsigned *d_queue = nullptr;
     RunParams *d_params = nullptr;
     unsigned long long *d_phase = nullptr;
@@ -879,15 +923,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         ncols += nc;
     }
     hipStream_t st = h->stream;
-    if (h->d_table) { (void)hipFree(h->d_table); h->d_table = nullptr; }
-    if (h->d_calcs) { (void)hipFree(h->d_calcs); h->d_calcs = nullptr; }
-    if (h->d_coloff) { (void)hipFree(h->d_coloff); h->d_coloff = nullptr; }
+    const auto t_host0 = std::chrono::steady_clock::now();
+    // result table and descriptors come from the allocation cache: a chunk loop re-runs with the same sizes
+    if (h->d_table) { h->pool.release(h->d_table, h->table_bytes); h->d_table = nullptr; }
+    if (h->d_calcs) { h->pool.release(h->d_calcs, h->calcs_bytes); h->d_calcs = nullptr; }
+    if (h->d_coloff) { h->pool.release(h->d_coloff, h->coloff_bytes); h->d_coloff = nullptr; }
     h->ncols = ncols;
     if (h->n_halo == 0) return 0;
-    HIPCHECK(hipMalloc((void **)&h->d_table, (size_t)h->n_halo * ncols * 8));
-    HIPCHECK(hipMalloc((void **)&h->d_calcs, (size_t)n_calcs * sizeof(soap_calc_desc)));
-    HIPCHECK(hipMalloc((void **)&h->d_coloff, (size_t)n_calcs * 4));
-    HIPCHECK(hipMemsetAsync(h->d_table, 0, (size_t)h->n_halo * ncols * 8, st));
+    h->table_bytes = (size_t)h->n_halo * ncols * 8;
+    h->calcs_bytes = (size_t)n_calcs * sizeof(soap_calc_desc);
+    h->coloff_bytes = (size_t)n_calcs * 4;
+    HIPCHECK(h->pool.alloc((void **)&h->d_table, h->table_bytes));
+    HIPCHECK(h->pool.alloc((void **)&h->d_calcs, h->calcs_bytes));
+    HIPCHECK(h->pool.alloc((void **)&h->d_coloff, h->coloff_bytes));
+    // (the table is not cleared here: every workgroup zeroes the row of a halo before it starts on it)
     HIPCHECK(hipMemcpyAsync(h->d_calcs, calcs, (size_t)n_calcs * sizeof(soap_calc_desc), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(h->d_coloff, coloff.data(), (size_t)n_calcs * 4, hipMemcpyHostToDevice, st));
 
@@ -942,23 +991,46 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (h->cfg.n_workgroups > 0) { groups[0] = h->cfg.n_workgroups * 4; groups[1] = h->cfg.n_workgroups; groups[2] = std::max(1, h->cfg.n_workgroups / 4); }
     for (int k = 0; k < 3; k++) caps[k] = std::min(caps[k], cap_max);
     std::vector<long long> est(h->n_halo);
+    const auto t_host0b = std::chrono::steady_clock::now();
     {
         long long *d_est;
         HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
-        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK - 1) / BLK)), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est);
+        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est);
         HIPCHECK(hipMemcpyAsync(est.data(), d_est, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         h->pool.release(d_est, (size_t)h->n_halo * 8);
     }
-    std::vector<int> todo[3];
-    for (long long i = 0; i < h->n_halo; i++) {
-        long long nb = est[i];
-        todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
-    }
+    const auto t_host1 = std::chrono::steady_clock::now();
     // heaviest first inside every class (the reference orders by bound-particle count for the same
-    // reason, chunk_tasks.py:118-120); ties keep the staged order
-    for (int k = 0; k < 3; k++)
-        std::stable_sort(todo[k].begin(), todo[k].end(), [&](int a, int b) { return est[a] > est[b]; });
+    // reason, chunk_tasks.py:118-120); ties keep the staged order.  One sort of packed (estimate, row) keys.
+    std::vector<int> todo[3];
+    {
+        // LSD radix sort (3 x 11 bits) of the row numbers by estimate: rows enter in descending order and
+        // the ascending result is read backwards, which gives descending estimates with ties in staged order
+        const size_t n = (size_t)h->n_halo;
+        std::vector<unsigned> a(n), b(n), e32(n);
+        for (size_t i = 0; i < n; i++) {
+            e32[i] = (unsigned)std::min<long long>(std::max<long long>(est[i], 0), 0xffffffffLL);
+            a[i] = (unsigned)(n - 1 - i);
+        }
+        for (int pass = 0; pass < 3; pass++) {
+            const int shift = 11 * pass;
+            size_t cnt[2049] = {0};
+            for (size_t i = 0; i < n; i++) cnt[((e32[a[i]] >> shift) & 2047u) + 1]++;
+            for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
+            for (size_t i = 0; i < n; i++) b[cnt[(e32[a[i]] >> shift) & 2047u]++] = a[i];
+            a.swap(b);
+        }
+        for (size_t r = n; r-- > 0;) {
+            const unsigned i = a[r];
+            const long long nb = e32[i];
+            todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
+        }
+    }
+    const auto t_host2 = std::chrono::steady_clock::now();
+    h->ms_host_setup = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
+    h->ms_host_pre = std::chrono::duration<double, std::milli>(t_host0b - t_host0).count();
+    h->ms_host_classify = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
     int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
@@ -995,7 +1067,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             C.nh += (long long)todo[k].size();
             if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
             else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(1024), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
             HIPCHECK(hipEventRecord(C.done, cs));
             HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         }
@@ -1028,6 +1100,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (int k = 0; k < 3; k++) todo[k].swap(next[k]);
     }
     h->ms_halo = ms_total;
+    h->ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     HIPCHECK(hipMemcpy(h->phase, h->d_phase, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1108,6 +1181,10 @@ int32_t soap_engine_phase_cycles(const soap_engine *h, uint64_t *out32) {
 double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!h || !name) return -1.0;
     if (!strcmp(name, "halo")) return h->ms_halo;
+    if (!strcmp(name, "run_setup")) return h->ms_host_setup;
+    if (!strcmp(name, "run_pre")) return h->ms_host_pre;
+    if (!strcmp(name, "run_classify")) return h->ms_host_classify;
+    if (!strcmp(name, "run_total")) return h->ms_host_total;
     if (!strcmp(name, "halo_wave")) return h->cls[0].ms;
     if (!strcmp(name, "halo_wg256")) return h->cls[1].ms;
     if (!strcmp(name, "halo_wg1024")) return h->cls[2].ms;

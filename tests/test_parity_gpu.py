@@ -187,7 +187,7 @@ def test_small_slab_triggers_retry_path(built_library):
     t1, t2 = o1[4]["table"], o2[4]["table"]
     assert np.allclose(t1, t2, rtol=1e-11, atol=1e-9)
     assert np.array_equal(t1[:, 6], t2[:, 6]) and np.array_equal(t1[:, 31 + 3], t2[:, 31 + 3])
-    assert np.array_equal(o1[4]["stats"], o2[4]["stats"])
+    assert np.array_equal(o1[4]["stats"][:, :3], o2[4]["stats"][:, :3])   # column 3 is a clock
     e1.close()
     e2.close()
 
