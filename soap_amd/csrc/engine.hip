@@ -135,6 +135,7 @@ SOAP_DEV double dpp_f64(double v) {
 #define DPP_ROW_HALF_MIRROR 0x141
 #define DPP_ROW_MIRROR 0x140
 #define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_ROR(n) (0x120 + (n))
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
 
@@ -144,28 +145,94 @@ SOAP_DEV double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// sum over the 64 lanes, same value returned to every lane (fixed association)
+// gfx950 lane swaps across rows: v_permlane16_swap exchanges the odd 16-lane rows of one register with the
+// even rows of another, v_permlane32_swap the upper half of one with the lower half of another.  Fed the
+// same register twice they return (even-row data everywhere, odd-row data everywhere) resp. (lower-half data
+// everywhere, upper-half data everywhere): a cross-row butterfly step in two VALU instructions per dword,
+// no LDS crossbar (ds_bpermute) round trip.
+SOAP_DEV void rows16_f64(double v, double &even, double &odd) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    even = __hiloint2double(rh[0], rl[0]);
+    odd = __hiloint2double(rh[1], rl[1]);
+}
+SOAP_DEV void halves32_f64(double v, double &lower, double &upper) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    lower = __hiloint2double(rh[0], rl[0]);
+    upper = __hiloint2double(rh[1], rl[1]);
+}
+
+// Wave totals of FOUR values for the price of one: v_permlane32_swap(x, y) leaves x = {x[0:31], y[0:31]} and
+// y = {x[32:63], y[32:63]}, so x + y holds the half-sums of x in the lower and those of y in the upper 32
+// lanes; the same step on 16-lane rows packs four values, one per row, and the in-row DPP butterfly
+// finishes all four together.  Returns a register whose row r (lanes 16r..16r+15) holds the total of v_r.
+SOAP_DEV double swap32_add(double x, double y) {
+    auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+SOAP_DEV double swap16_add(double x, double y) {
+    auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+SOAP_DEV double wave_sum4(double v0, double v1, double v2, double v3) {
+    double a = swap32_add(v0, v2);   // lower half: v0, upper half: v2
+    double b = swap32_add(v1, v3);   // lower half: v1, upper half: v3
+    double c = swap16_add(a, b);     // rows: v0, v1, v2, v3
+    c += dpp_f64<DPP_QUAD_XOR1>(c);
+    c += dpp_f64<DPP_QUAD_XOR2>(c);
+    c += dpp_f64<DPP_ROW_HALF_MIRROR>(c);
+    c += dpp_f64<DPP_ROW_MIRROR>(c);
+    return c;
+}
+// store the four totals of wave_sum4 into dst[k0..k3] (one lane per row writes)
+SOAP_DEV void put4(double *dst, double packed, int k0, int k1, int k2, int k3) {
+    const int lane = threadIdx.x & 63, row = lane >> 4;
+    if ((lane & 15) == 0) dst[row == 0 ? k0 : (row == 1 ? k1 : (row == 2 ? k2 : k3))] = packed;
+}
+
+// sum over the 64 lanes, same value returned to every lane (fixed association:
+// ((row0 + row1) + (row2 + row3)) of the in-row butterflies)
 SOAP_DEV double wave_sum(double v) {
     v += dpp_f64<DPP_QUAD_XOR1>(v);
     v += dpp_f64<DPP_QUAD_XOR2>(v);
     v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f64<DPP_ROW_MIRROR>(v);        // every lane of a 16-lane row holds the row sum
-    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+    double a, b;
+    rows16_f64(v, a, b);
+    v = a + b;
+    halves32_f64(v, a, b);
+    return a + b;
 }
 SOAP_DEV double wave_max(double v) {
     v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
     v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
     v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
     v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
-    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+    double a, b;
+    rows16_f64(v, a, b);
+    v = fmax(a, b);
+    halves32_f64(v, a, b);
+    return fmax(a, b);
 }
 SOAP_DEV long long wave_min_ll(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        long long u = __shfl_xor(v, o, 64);
-        v = u < v ? u : v;
-    }
-    return v;
+    // same butterfly on the bit pattern (a double register pair is just 64 bits here)
+    auto mn = [](long long x, long long y) { return y < x ? y : x; };
+    auto asd = [](long long x) { return __longlong_as_double(x); };
+    auto asl = [](double x) { return __double_as_longlong(x); };
+    v = mn(v, asl(dpp_f64<DPP_QUAD_XOR1>(asd(v))));
+    v = mn(v, asl(dpp_f64<DPP_QUAD_XOR2>(asd(v))));
+    v = mn(v, asl(dpp_f64<DPP_ROW_HALF_MIRROR>(asd(v))));
+    v = mn(v, asl(dpp_f64<DPP_ROW_MIRROR>(asd(v))));
+    double a, b;
+    rows16_f64(asd(v), a, b);
+    v = mn(asl(a), asl(b));
+    halves32_f64(asd(v), a, b);
+    return mn(asl(a), asl(b));
 }
 // inclusive scan inside a wave (row_shr with zero fill inside rows of 16, then row broadcasts)
 SOAP_DEV double wave_scan(double v, int lane) {
@@ -358,6 +425,7 @@ __global__ void k_reorder(const unsigned *sort_idx, long long n, const double *p
 // per-halo kernel
 // ------------------------------------------------------------------------------------------
 #define NACC 40
+#define PREFB 16        // calculations whose prefix moments are finalised together
 enum {
     A_N0 = 0, A_N1, A_N2, A_N3,        // counts per type slot
     A_M0 = 4, A_M1, A_M2, A_M3,        // mass per type slot
@@ -385,7 +453,7 @@ enum {
 #define GWG 64
 #define GCH 1024
 #define SORT_NBMAX 64
-#define GLB 2
+#define GLB 4
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 namespace g64 {
 #include "halo_kernel.inc"
@@ -423,7 +491,7 @@ namespace g256 {
 #define GNW (G3T / 64)
 #define GWG G3T
 #define GCH 8192
-#define SORT_NBMAX 512
+#define SORT_NBMAX 1024
 #define GLB (G3T == 1024 ? 4 : 2)
 #define GSYNC() __syncthreads()
 namespace g1024 {
