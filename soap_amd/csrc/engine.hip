@@ -234,6 +234,29 @@ SOAP_DEV long long wave_min_ll(long long v) {
     halves32_f64(asd(v), a, b);
     return mn(asl(a), asl(b));
 }
+// DPP move that leaves a lane's own value where the pattern has no source lane (identity for scans with an
+// operator other than +)
+template <int CTRL, int ROW_MASK = 0xf>
+SOAP_DEV double dpp_f64_keep(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_WAVE_SHR1 0x138     // wave_shr:1 (whole wavefront, lane 0 keeps its value)
+// inclusive prefix arg-max inside a wave: (v, s) becomes the pair with the largest v among lanes <= this one,
+// ties going to the lowest lane ("first maximum")
+SOAP_DEV void wave_scan_argmax(double &v, double &s) {
+#define ARGMAX_STEP(CTRL, MASK) { double pv = dpp_f64_keep<CTRL, MASK>(v), ps = dpp_f64_keep<CTRL, MASK>(s); if (!(v > pv)) { v = pv; s = ps; } }
+    ARGMAX_STEP(DPP_ROW_SHR(1), 0xf)
+    ARGMAX_STEP(DPP_ROW_SHR(2), 0xf)
+    ARGMAX_STEP(DPP_ROW_SHR(4), 0xf)
+    ARGMAX_STEP(DPP_ROW_SHR(8), 0xf)
+    ARGMAX_STEP(DPP_ROW_BCAST15, 0xa)
+    ARGMAX_STEP(DPP_ROW_BCAST31, 0xc)
+#undef ARGMAX_STEP
+}
+
 // inclusive scan inside a wave (row_shr with zero fill inside rows of 16, then row broadcasts)
 SOAP_DEV double wave_scan(double v, int lane) {
     (void)lane;
