@@ -12,6 +12,9 @@ wl = dict(bench.WORKLOADS["c3"], n_part=10_000_000, n_halo=10_000)
 sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1, device="cuda:0")
 cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
 hn = {k: v.cpu().numpy() for k, v in halos.items()}
+if os.environ.get("LAT_MAXNB"):
+    keep = hn["nr_bound_part"] < int(os.environ["LAT_MAXNB"])
+    hn = {k: v[keep] for k, v in hn.items()}
 H = len(hn["index"])
 for nwg in [int(x) for x in os.environ.get('LAT_NWG', '1,16,512').split(',')]:
     eng = halo_tasks.make_engine(sc, device=0, n_workgroups=nwg)

@@ -269,6 +269,17 @@ SOAP_DEV double wave_scan(double v, int lane) {
     return v;
 }
 
+// inclusive running maximum inside a wave (values >= 0: the zero fill of row_shr is the identity)
+SOAP_DEV double wave_scan_max(double v) {
+    v = fmax(v, dpp_f64<DPP_ROW_SHR(1)>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_SHR(2)>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_SHR(4)>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_SHR(8)>(v));
+    v = fmax(v, dpp_f64_keep<DPP_ROW_BCAST15, 0xa>(v));
+    v = fmax(v, dpp_f64_keep<DPP_ROW_BCAST31, 0xc>(v));
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // mesh build kernels  (shared_mesh.py:33-114)
 // ------------------------------------------------------------------------------------------
@@ -468,70 +479,6 @@ enum {
 
 #define GAS __attribute__((address_space(1)))
 
-// ---- three instantiations of the per-halo code (halo_kernel.inc) ---------------------------------
-// a wavefront-level "barrier": LDS and global accesses of one wave are issued in order, so only the
-// compiler and outstanding memory operations have to be fenced
-#define GRP 64
-#define GNW 1
-#define GWG 64
-#define GCH 1024
-#define SORT_NBMAX 64
-#define GLB 4
-#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-namespace g64 {
-#include "halo_kernel.inc"
-}
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GLB
-#undef GSYNC
-
-#define GRP 256
-#define GNW 4
-#define GWG 256
-#define GCH 4096
-#define SORT_NBMAX 256
-#define GLB 2
-#define GSYNC() __syncthreads()
-namespace g256 {
-#include "halo_kernel.inc"
-}
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GLB
-#undef GSYNC
-
-#ifndef G3T
-#define G3T 1024   // threads of the largest class (512 threads x 256 VGPRs measured slower: 35 vs 29 ms on C3)
-#endif
-#define GRP G3T
-#define GNW (G3T / 64)
-#define GWG G3T
-#define GCH 8192
-#define SORT_NBMAX 1024
-#define GLB (G3T == 1024 ? 4 : 2)
-#define GSYNC() __syncthreads()
-namespace g1024 {
-#include "halo_kernel.inc"
-}
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GLB
-#undef GSYNC
-
-// Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
-// (an upper bound of what the halo kernel will have to sort).  Used to pick the thread-group class of
-// each halo and to start the heaviest halos first: bound-particle counts alone miss small halos that sit
-// next to a giant (their search sphere swallows the giant's cells).
 struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexed private array)
     unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     __device__ __forceinline__ void set_range(int lo, int hi) {   // bits [lo, hi]
@@ -544,6 +491,17 @@ struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexe
             if (k == 0) w0 |= m; else if (k == 1) w1 |= m; else if (k == 2) w2 |= m; else w3 |= m;
         }
     }
+    __device__ __forceinline__ int count() const { return __popcll(w0) + __popcll(w1) + __popcll(w2) + __popcll(w3); }
+    // position of the n-th set bit (n < count())
+    __device__ __forceinline__ int nth(int n) const {
+        unsigned long long w = w0;
+        int base = 0, c = __popcll(w);
+        if (n >= c) { n -= c; w = w1; base = 64; c = __popcll(w);
+            if (n >= c) { n -= c; w = w2; base = 128; c = __popcll(w);
+                if (n >= c) { n -= c; w = w3; base = 192; } } }
+        for (int q = 0; q < n; q++) w &= w - 1;
+        return base + __ffsll((long long)w) - 1;
+    }
     __device__ __forceinline__ bool get(int q) const {
         const int k = q >> 6;
         const unsigned long long w = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
@@ -551,6 +509,77 @@ struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexe
     }
 };
 
+
+// ---- three instantiations of the per-halo code (halo_kernel.inc) ---------------------------------
+// a wavefront-level "barrier": LDS and global accesses of one wave are issued in order, so only the
+// compiler and outstanding memory operations have to be fenced
+#define GRP 64
+#define GNW 1
+#define GWG 64
+#define GCH 1024
+#define SORT_NBMAX 64
+#define GLB 4
+#define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+namespace g64 {
+#include "halo_kernel.inc"
+}
+#undef GRP
+#undef GNW
+#undef GWG
+#undef GCH
+#undef SORT_NBMAX
+#undef GATTR
+#undef GLB
+#undef GSYNC
+
+#define GRP 256
+#define GNW 4
+#define GWG 256
+#define GCH 4096
+#define SORT_NBMAX 256
+#define GLB 2
+#define GATTR __launch_bounds__(GRP, GLB)
+#define GSYNC() __syncthreads()
+namespace g256 {
+#include "halo_kernel.inc"
+}
+#undef GRP
+#undef GNW
+#undef GWG
+#undef GCH
+#undef SORT_NBMAX
+#undef GATTR
+#undef GLB
+#undef GSYNC
+
+#ifndef G3T
+#define G3T 1024   // threads of the largest class (512 threads x 256 VGPRs measured slower: 35 vs 29 ms on C3)
+#endif
+#define GRP G3T
+#define GNW (G3T / 64)
+#define GWG G3T
+#define GCH 8192
+#define SORT_NBMAX 1024
+#define GLB (G3T == 1024 ? 4 : 2)
+#define GATTR __launch_bounds__(GRP, GLB)
+#define GSYNC() __syncthreads()
+namespace g1024 {
+#include "halo_kernel.inc"
+}
+#undef GRP
+#undef GNW
+#undef GWG
+#undef GCH
+#undef SORT_NBMAX
+#undef GATTR
+#undef GLB
+#undef GSYNC
+
+// Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
+// (an upper bound of what the halo kernel will have to sort).  Used to pick the thread-group class of
+// each halo and to start the heaviest halos first: bound-particle counts alone miss small halos that sit
+// next to a giant (their search sphere swallows the giant's cells).
 // one wavefront per halo: the lanes share the (k, j) mesh rows of the sphere's bounding cells, so the
 // dependent cell_offset lookups of one halo are in flight together
 __global__ void k_estimate(const RunParams *Pp, long long *est) {
@@ -591,15 +620,10 @@ __global__ void k_estimate(const RunParams *Pp, long long *est) {
             run_lo[nrun] = i0; run_hi[nrun] = i1; nrun++;
             i0 = i1 + 1;
         }
-        const int nk = __popcll(mk[2].w0) + __popcll(mk[2].w1) + __popcll(mk[2].w2) + __popcll(mk[2].w3);
-        const int nj = __popcll(mk[1].w0) + __popcll(mk[1].w1) + __popcll(mk[1].w2) + __popcll(mk[1].w3);
+        const int nk = mk[2].count(), nj = mk[1].count();
         for (int pair = lane; pair < nk * nj; pair += 64) {
             const int ak = pair / nj, aj = pair - ak * nj;
-            // ak-th set bit of the z mask, aj-th set bit of the y mask
-            int k = -1, j = -1, seen = 0;
-            for (int q = 0; q < res; q++) if (mk[2].get(q)) { if (seen == ak) { k = q; break; } seen++; }
-            seen = 0;
-            for (int q = 0; q < res; q++) if (mk[1].get(q)) { if (seen == aj) { j = q; break; } seen++; }
+            const int k = mk[2].nth(ak), j = mk[1].nth(aj);   // ak-th set bit of the z mask, aj-th of the y mask
             const long long rowbase = (long long)res * j + (long long)res * res * k;
             for (int r = 0; r < nrun; r++)
                 tot += (long long)(T.cell_offset[rowbase + run_hi[r] + 1] - T.cell_offset[rowbase + run_lo[r]]);
