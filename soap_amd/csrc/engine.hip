@@ -69,11 +69,12 @@ struct TypeDev {
     long long n;
     int res;
     int grnr64;
-    const double *x, *y, *z, *vx, *vy, *vz, *m;
+    const double *x, *y, *z;      // coordinates in mesh-cell order (SoA): what the candidate stream reads
+    const double *vel, *mass;     // the caller's arrays (AoS velocities), indexed through `orig`
     const int *grnr32;
     const long long *grnr64p;
     const long long *fof;
-    const unsigned *orig;
+    const unsigned *orig;         // original index of the particle at cell-ordered position p
     const unsigned *cell_offset;  // res^3 + 1 entries
     double pos_min[3], pos_max[3], cell_size[3];
 };
@@ -433,25 +434,16 @@ __global__ void k_scatter(const unsigned *cell, long long n, const unsigned *off
     }
 }
 
-// physical reorder into cell order: AoS inputs -> SoA outputs
-__global__ void k_reorder(const unsigned *sort_idx, long long n, const double *pos,
-                          const double *vel, const double *mass, const void *grnr, int grnr_bytes,
-                          const long long *fof, double *x, double *y, double *z, double *vx,
-                          double *vy, double *vz, double *m, int *g32, long long *g64,
-                          long long *f) {
+// physical reorder of the coordinates into cell order (AoS input -> SoA output).  Velocities, masses and
+// ids stay where the caller put them: only selected particles ever need them, and those are gathered
+// through `orig` when a halo's slab is built.
+__global__ void k_reorder(const unsigned *sort_idx, long long n, const double *pos, double *x, double *y, double *z) {
     for (long long p = blockIdx.x * (long long)BLK + threadIdx.x; p < n;
          p += (long long)gridDim.x * BLK) {
         long long i = sort_idx[p];
         x[p] = pos[3 * i];
         y[p] = pos[3 * i + 1];
         z[p] = pos[3 * i + 2];
-        vx[p] = vel[3 * i];
-        vy[p] = vel[3 * i + 1];
-        vz[p] = vel[3 * i + 2];
-        m[p] = mass[i];
-        if (grnr_bytes == 4) g32[p] = ((const int *)grnr)[i];
-        else g64[p] = ((const long long *)grnr)[i];
-        f[p] = fof[i];
     }
 }
 
@@ -644,7 +636,8 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
         double r = sqrt((wx * wx + wy * wy) + wz * wz);
         bool in = strict ? (r < R) : (r <= R);
         if (in && bound_only) {
-            long long g = T.grnr64 ? T.grnr64p[p] : (long long)T.grnr32[p];
+            const unsigned o = T.orig[p];
+            long long g = T.grnr64 ? T.grnr64p[o] : (long long)T.grnr32[o];
             in = (g == hindex);
         }
         if (in) {
@@ -675,18 +668,18 @@ struct TypeHost {
     long long n = 0;
     int res = 0;
     int grnr64 = 0;
-    double *x = nullptr, *y = nullptr, *z = nullptr, *vx = nullptr, *vy = nullptr, *vz = nullptr,
-           *m = nullptr;
-    int *g32 = nullptr;
-    long long *g64 = nullptr, *fof = nullptr;
+    double *x = nullptr, *y = nullptr, *z = nullptr;
+    // velocities / masses / ids: the caller's device arrays, or the engine's device copies of host arrays
+    const double *vel = nullptr, *mass = nullptr;
+    const int *g32 = nullptr;
+    const long long *g64 = nullptr, *fof = nullptr;
+    std::vector<std::pair<void *, size_t>> owned;   // device copies the engine made (host inputs)
     unsigned *orig = nullptr, *cell_offset = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
     void release(DevPool &pool) {
-        void *d8[] = {x, y, z, vx, vy, vz, m};
+        void *d8[] = {x, y, z};
         for (void *p : d8) pool.release(p, (size_t)n * 8);
-        pool.release(g32, (size_t)n * 4);
-        pool.release(g64, (size_t)n * 8);
-        pool.release(fof, (size_t)n * 8);
+        for (auto &o : owned) pool.release(o.first, o.second);
         pool.release(orig, (size_t)n * 4);
         pool.release(cell_offset, ((size_t)res * res * res + 1) * 4);
         *this = TypeHost();
@@ -894,6 +887,12 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
         dgr = d; dfof = (const long long *)e;
     }
     auto cleanup = [&]() { for (auto &p : tmp) pool.release(p.first, p.second); tmp.clear(); };
+    auto keep_payload = [&]() {   // the coordinate copy goes back to the cache, the rest lives as long as the mesh
+        if (tmp.empty()) return;
+        pool.release(tmp[0].first, tmp[0].second);
+        for (size_t k = 1; k < tmp.size(); k++) T.owned.push_back(tmp[k]);
+        tmp.clear();
+    };
 
     HIPCHECK(hipEventRecord(h->ev0, st));
     // bounding box (shared_mesh.py:33-61)
@@ -943,16 +942,13 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     HIPCHECK(hipEventRecord(h->ev1, st));
 
     // reorder into cell order
-    double **dp[] = {&T.x, &T.y, &T.z, &T.vx, &T.vy, &T.vz, &T.m};
+    double **dp[] = {&T.x, &T.y, &T.z};
     for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
-    if (T.grnr64) HIPCHECK(pool.alloc((void **)&T.g64, (size_t)n * 8));
-    else HIPCHECK(pool.alloc((void **)&T.g32, (size_t)n * 4));
-    HIPCHECK(pool.alloc((void **)&T.fof, (size_t)n * 8));
+    T.vel = dvel; T.mass = dmass; T.fof = dfof;
+    if (T.grnr64) T.g64 = (const long long *)dgr; else T.g32 = (const int *)dgr;
     hipEvent_t ev2;
     HIPCHECK(hipEventCreate(&ev2));
-    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLK), 0, st, d_sortidx, (long long)n, dpos, dvel,
-                       dmass, dgr, (int)grnr_bytes, dfof, T.x, T.y, T.z, T.vx, T.vy, T.vz, T.m,
-                       T.g32, T.g64, T.fof);
+    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLK), 0, st, d_sortidx, (long long)n, dpos, T.x, T.y, T.z);
     HIPCHECK(hipEventRecord(ev2, st));
     HIPCHECK(hipStreamSynchronize(st));
     hipError_t le = hipGetLastError();
@@ -966,7 +962,7 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     T.orig = d_sortidx;   // original index of the particle now at position p
     pool.release(d_cell, (size_t)n * 4); pool.release(d_count, (size_t)ncell * 4);
     pool.release(d_cursor, (size_t)ncell * 4); pool.release(d_tilesum, (size_t)ntiles * 4);
-    cleanup();
+    keep_payload();
     return 0;
 }
 
@@ -1065,7 +1061,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         const TypeHost &T = h->t[t];
         TypeDev &D = P.t[t];
         D.n = T.n; D.res = T.res; D.grnr64 = T.grnr64;
-        D.x = T.x; D.y = T.y; D.z = T.z; D.vx = T.vx; D.vy = T.vy; D.vz = T.vz; D.m = T.m;
+        D.x = T.x; D.y = T.y; D.z = T.z; D.vel = T.vel; D.mass = T.mass;
         D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset;
         for (int d = 0; d < 3; d++) { D.pos_min[d] = T.pos_min[d]; D.pos_max[d] = T.pos_max[d]; D.cell_size[d] = T.cell_size[d]; }
         P.soft[t] = h->cfg.softening[t];
