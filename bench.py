@@ -213,6 +213,16 @@ def main():
         t_halo = float(np.mean(ms_halo)) * 1e-3
         b_alg = n_cand * B_PARTICLE + H * ncols * 8
         achieved = b_alg / t_halo / 1e9
+        # HBM-side bytes of the halo kernels from the committed PMC passes (rocprofv3 cannot run inside the
+        # bench): only quoted when the workload is the one that was profiled
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "round1", "final_c3_hbm_traffic.json")) as f:
+                pj = json.load(f)
+            if pj.get("workload") == wl["name"] and pj.get("seed") == args.seed and world == 1:
+                traffic = pj["traffic_bytes_per_step_corrected"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         line = {
             "metric": "particle_aperture_evals_per_s",
             "value": evals_all * args.steps / dt,
@@ -239,9 +249,11 @@ def main():
                                 int(engine.kernel_ms("n_wg1024"))],
             "roofline": {
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes": b_alg,
-                "note": "sum_h n_cand(h)*68 B + H*P*8 B per launch / HIP-event duration of k_halo",
+                "note": "sum_h n_cand(h)*68 B + H*P*8 B per step / HIP-event duration of the three concurrent k_halo "
+                        "launches (g64/g256/g1024); traffic = 2*FETCH_SIZE + WRITE_SIZE of those launches from "
+                        "profiles/round1/final_c3_hbm_traffic.json (separate --pmc passes, gfx950 read correction)",
             },
             "reorder_roofline": {
                 "achieved": 2 * wl["n_part"] * B_PARTICLE / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,

@@ -123,6 +123,11 @@ int32_t soap_engine_destroy(soap_engine *h);
  *   fof            [n]    FOFGroupIDs int64
  *   resolution     mesh cells per dimension (chunk_tasks.py:299-302 computes it)
  *   on_device      0: host pointers, 1: device (HBM) pointers on cfg.device
+ * Only the coordinates are physically reordered into cell order; velocities, masses and ids are read in
+ * place, through the reorder permutation, for the particles a halo selects.  Lifetime: with
+ * on_device == 1 the vel / mass / grnr / fof arrays must stay valid and unchanged until the next
+ * soap_engine_stage_particles for this slot or soap_engine_destroy (pos may be reused as soon as this
+ * call returns); with on_device == 0 the engine keeps its own device copies.
  */
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n,
                                     const double *pos, const double *vel, const double *mass,
