@@ -464,7 +464,53 @@ SCHEMA = {
     "concentration_unsoft": (1, np.float32),
     "Mfrac_satellites": (1, np.float32),
     "Mfrac_external": (1, np.float32),
+    # gas / star / baryon kinematics (property_table.py rows of SURVEY.md 8(a) a22, hydro part)
+    "com_gas": (3, np.float64),
+    "com_star": (3, np.float64),
+    "vcom_gas": (3, np.float32),
+    "vcom_star": (3, np.float32),
+    "Lgas": (3, np.float32),
+    "Lstar": (3, np.float32),
+    "Lbaryons": (3, np.float32),
+    "veldisp_matrix_gas": (6, np.float32),
+    "veldisp_matrix_star": (6, np.float32),
+    "proj_veldisp_gas": (1, np.float32),
+    "proj_veldisp_star": (1, np.float32),
+    "HalfMassRadiusGas": (1, np.float32),
+    "HalfMassRadiusStar": (1, np.float32),
+    "HalfMassRadiusBaryon": (1, np.float32),
 }
+
+
+def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxsize):
+    """
+    Gas, star and baryon (gas + star) kinematics of a selection, written into `out`:
+    centres of mass and velocities, angular momenta about the component's own centre-of-mass velocity,
+    velocity dispersion tensors, half-mass radii.  One restatement for the four particle-data classes:
+    SO_properties.py:716-783 (gas), :995-1087 (stars), :1225-1276 (baryons);
+    aperture_properties.py:1129-1217, :1283-1360, :1466-1474, :1645-1706, :3469-3548;
+    subhalo_properties.py (same bodies on the bound set).  Positions are relative to the halo centre.
+    Keys that the reference leaves as None (component mass zero) are simply not set.
+    """
+    gas, star = types == 0, types == 4
+    bar = gas | star
+    for key, sel in (("gas", gas), ("star", star)):
+        M = mass[sel].sum()
+        if M != 0:
+            f = mass[sel] / M
+            out[f"com_{key}"] = ((f[:, None] * position[sel]).sum(axis=0) + centre) % boxsize
+            vc = (f[:, None] * velocity[sel]).sum(axis=0)
+            out[f"vcom_{key}"] = vc
+            out[f"L{key}"] = get_angular_momentum(mass[sel], position[sel], velocity[sel], vc)
+            out[f"veldisp_matrix_{key}"] = get_velocity_dispersion_matrix(f, velocity[sel], vc)[0]
+    Mb = mass[bar].sum()
+    if Mb != 0:
+        fb = mass[bar] / Mb
+        vcb = (fb[:, None] * velocity[bar]).sum(axis=0)
+        out["Lbaryons"] = get_angular_momentum(mass[bar], position[bar], velocity[bar], vcb)
+    out["HalfMassRadiusGas"] = get_half_weight_radius(radius[gas], mass[gas], mass[gas].sum())
+    out["HalfMassRadiusStar"] = get_half_weight_radius(radius[star], mass[star], mass[star].sum())
+    out["HalfMassRadiusBaryon"] = get_half_weight_radius(radius[bar], mass[bar], Mb)
 
 
 def _store(result, group, key, val):
@@ -500,6 +546,8 @@ class SubhaloProperties:
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "Vmax_unsoft", "Vmax_soft", "R_vmax_unsoft", "spin_parameter",
         "HalfMassRadiusTot", "HalfMassRadiusDM", "veldisp_matrix_dm", "EncloseRadius",
+        "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
+        "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
     ]  # fmt: skip
 
     def __init__(self, units: Units, filters=DEFAULT_FILTERS, dmo=True):
@@ -581,6 +629,7 @@ class SubhaloProperties:
             out["EncloseRadius"] = np.max(radius)
         out["HalfMassRadiusTot"] = get_half_weight_radius(radius, mass, Mtot)
         out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
+        baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize)
 
         for key in self.property_list:
             _store(halo_result, g, key, out.get(key))
@@ -597,6 +646,7 @@ class SOProperties:
         "r", "Mtot", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Vmax_soft", "R_vmax_soft",
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
+        "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
     ]  # fmt: skip
 
     def __init__(self, units: Units, SOval: float, type: str = "mean",
@@ -780,6 +830,7 @@ class SOProperties:
             fdm = mass[dm] / M_t[1]
             vcom_dm = (fdm[:, None] * velocity[dm]).sum(axis=0)
             out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
+        baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize)
         if self.virial_definition:
             for key, rr in (("concentration_unsoft", radius),
                             ("concentration_soft", np.maximum(softening, radius))):  # fmt: skip
@@ -840,6 +891,8 @@ class ApertureProperties:
     property_list = [
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
+        "com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
+        "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
     ]  # fmt: skip
 
     def __init__(self, units: Units, radius_kpc: float, inclusive: bool, all_radii_kpc=None,
@@ -945,6 +998,7 @@ class ApertureProperties:
             out["veldisp_matrix_dm"] = get_velocity_dispersion_matrix(fdm, velocity[dm], vcom_dm)[0]
             out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
         out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
+        baryon_kinematics(out, mass, position, velocity, type_, radius, centre, u.boxsize)
         return out
 
 
@@ -956,7 +1010,9 @@ class ProjectedApertureProperties:
     :1491-1577, :1798-2002 -- DMO/basic subset; bound particles only."""
 
     property_list = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar",
-                     "Nbh", "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm"]  # fmt: skip
+                     "Nbh", "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm",
+                     "com_star", "proj_veldisp_gas", "proj_veldisp_star",
+                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]  # fmt: skip
 
     def __init__(self, units: Units, radius_kpc: float, all_radii_kpc=None,
                  halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
@@ -1052,6 +1108,22 @@ class ProjectedApertureProperties:
                 vc = (fdm * pv).sum()
                 out["proj_veldisp_dm"] = np.sqrt((fdm * (pv - vc) ** 2).sum())
             out["HalfMassRadiusDM"] = get_half_weight_radius(r[dm], m[dm], M_t[1])
+            # gas / stars / baryons in projection (projected_aperture_properties.py:739-786, :864-986,
+            # :1491-1577): star centre of mass, line-of-sight dispersions, half-mass radii in 2D radius
+            gas, star = t == 0, t == 4
+            if M_t[4] != 0:
+                fs = m[star] / M_t[4]
+                out["com_star"] = ((fs[:, None] * x[star]).sum(axis=0) + centre) % u.boxsize
+            for key, sel2, Mk in (("gas", gas, M_t[0]), ("star", star, M_t[4])):
+                if Mk != 0:
+                    fk = m[sel2] / Mk
+                    pvk = v[sel2, iproj]
+                    vck = (fk * pvk).sum()
+                    out[f"proj_veldisp_{key}"] = np.sqrt((fk * (pvk - vck) ** 2).sum())
+            bar = gas | star
+            out["HalfMassRadiusGas"] = get_half_weight_radius(r[gas], m[gas], M_t[0])
+            out["HalfMassRadiusStar"] = get_half_weight_radius(r[star], m[star], M_t[4])
+            out["HalfMassRadiusBaryon"] = get_half_weight_radius(r[bar], m[bar], m[bar].sum())
             outs[proj] = out
         return outs
 

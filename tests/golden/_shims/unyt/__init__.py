@@ -66,6 +66,9 @@ class unyt_array(np.ndarray):
             return res.view(unyt_array)
         if isinstance(res, tuple):
             return tuple(r.view(unyt_array) if isinstance(r, np.ndarray) else r for r in res)
+        if isinstance(res, np.floating):
+            # scalar results of functions applied to quantities stay quantities (np.linalg.norm(L).units)
+            return np.asarray(res).view(unyt_array)
         return res
 
     @property

@@ -245,7 +245,8 @@ def main():
                 continue
             for name in ["r", "Mtot", "Mtotpart", "com", "vcom", "Vmax_soft", "R_vmax_soft", "spin_parameter",
                          "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar", "Nbh",
-                         "Mgas", "Mstar", "Mbh_dynamical", "concentration_unsoft", "concentration_soft"]:
+                         "Mgas", "Mstar", "Mbh_dynamical", "concentration_unsoft", "concentration_soft",
+                         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # apertures
@@ -255,14 +256,18 @@ def main():
                                          soft, U(boxsize), cosmology)
             case[f"{tag}/radius"] = np.array(rap)
             for name in ["Mtot", "Mdm", "Mgas", "Mstar", "Mbh_dynamical", "Ndm", "Ngas", "Nstar", "Nbh", "com",
-                         "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft"]:
+                         "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
+                         "com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas",
+                         "veldisp_matrix_star", "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # bound subhalo
         pp = SH.SubhaloParticleData(input_halo, udata, types_present, None, None, DS, soft, U(boxsize), cosmology)
         for name in ["Mtot", "Mdm", "Mgas", "Mstar", "Mbh_dynamical", "Ndm", "Ngas", "Nstar", "Nbh", "com", "vcom",
                      "Ldm", "veldisp_matrix_dm", "Vmax_unsoft", "R_vmax_unsoft", "Vmax_soft", "spin_parameter",
-                     "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius"]:
+                     "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius",
+                     "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
+                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
             val = getattr(pp, name)
             case[f"SH/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # projected
@@ -272,7 +277,8 @@ def main():
         for proj in ("projx", "projy", "projz"):
             sp = PJ.SingleProjectionProjectedApertureParticleData(pp, proj)
             for name in ["Mtot", "Mdm", "Ndm", "Ngas", "Nstar", "Nbh", "com", "vcom", "HalfMassRadiusDM",
-                         "proj_veldisp_dm"]:
+                         "proj_veldisp_dm", "com_star", "proj_veldisp_gas", "proj_veldisp_star",
+                         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
                 val = getattr(sp, name)
                 case[f"PJ/{proj}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         cases.append(case)

@@ -145,6 +145,7 @@ def test_particle_data_classes_match_reference():
             _check(tag, out, c, ["r", "Mtot", "com", "vcom", "Vmax_soft", "R_vmax_soft", "spin_parameter",
                                  "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar",
                                  "Nbh", "Mgas", "Mstar", "Mbh_dynamical"])  # fmt: skip
+            _check(tag, out, c, ["com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"])
             # concentration: the reference rounds to float32 (SO_properties.py:2735)
             _check(tag, out, c, ["concentration_unsoft", "concentration_soft"], exact=False)
         # --- apertures
@@ -155,9 +156,14 @@ def test_particle_data_classes_match_reference():
             _check(tag, out, c, ["Mtot", "Mdm", "Mgas", "Mstar", "Mbh_dynamical", "Ndm", "Ngas", "Nstar",
                                  "Nbh", "com", "vcom", "Ldm", "HalfMassRadiusDM", "Vmax_soft",
                                  "R_vmax_soft"])  # fmt: skip
-            want = c[f"{tag}/veldisp_matrix_dm"]
-            if not np.all(np.isnan(want)):
-                assert np.array_equal(np.float32(out["veldisp_matrix_dm"]).astype(np.float64), want)
+            _check(tag, out, c, ["com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "HalfMassRadiusGas",
+                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
+            for vk in ("veldisp_matrix_dm", "veldisp_matrix_gas", "veldisp_matrix_star"):
+                want = c[f"{tag}/{vk}"]
+                if not np.all(np.isnan(want)):   # the reference's result buffer is float32
+                    assert np.array_equal(np.float32(out[vk]).astype(np.float64), want), (i, tag, vk)
+                else:
+                    assert vk not in out
         # --- bound subhalo
         sh = ho.SubhaloProperties(u, dmo=False)
         res = {}
@@ -165,20 +171,26 @@ def test_particle_data_classes_match_reference():
         out = {k.split("/", 1)[1]: v.raw for k, v in res.items() if k != "_counts"}
         for key in ("Mtot", "Mdm", "Mgas", "Mstar", "Mbh_dynamical", "Ndm", "Ngas", "Nstar", "Nbh", "com",
                     "vcom", "Ldm", "Vmax_unsoft", "R_vmax_unsoft", "Vmax_soft", "spin_parameter",
-                    "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius"):  # fmt: skip
+                    "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius", "com_star", "Lgas", "Lstar",
+                    "Lbaryons", "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"):  # fmt: skip
             want = c[f"SH/{key}"]
             got = out[key]
             if np.all(np.isnan(want)):
                 assert np.all(got == 0)
             else:
                 assert np.allclose(got.reshape(want.shape), want, rtol=RTOL, atol=0), (i, key, got, want)
-        want = c["SH/veldisp_matrix_dm"]
-        if not np.all(np.isnan(want)):
-            assert np.array_equal(np.float32(out["veldisp_matrix_dm"]).astype(np.float64), want)
+        for vk in ("veldisp_matrix_dm", "veldisp_matrix_gas", "veldisp_matrix_star"):
+            want = c[f"SH/{vk}"]
+            if not np.all(np.isnan(want)):
+                assert np.array_equal(np.float32(out[vk]).astype(np.float64), want), (i, vk)
+            else:
+                assert np.all(out[vk] == 0)
         # --- projected apertures
         pj = ho.ProjectedApertureProperties(u, 50.0, dmo=False)
         outs = pj._calculate(input_halo, float(c["PJ/radius"]), data)
         for proj in ("projx", "projy", "projz"):
             _check(f"PJ/{proj}", outs[proj], c, ["Mtot", "Mdm", "Ndm", "Ngas", "Nstar", "Nbh", "com", "vcom",
-                                                "HalfMassRadiusDM", "proj_veldisp_dm"])  # fmt: skip
+                                                "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
+                                                "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
+                                                "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
     assert n_so > 20 and n_ap > 40
