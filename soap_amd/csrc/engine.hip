@@ -107,6 +107,7 @@ struct RunParams {
     int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
     double first_factor;   // first sorted superset reaches first_factor * search_radius
     int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
+    int hydro;             // gas or star particles staged: the baryon kinematics are computed
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -450,8 +451,9 @@ __global__ void k_reorder(const unsigned *sort_idx, long long n, const double *p
 // ------------------------------------------------------------------------------------------
 // per-halo kernel
 // ------------------------------------------------------------------------------------------
-#define NACC 40
-#define PREFB 16        // calculations whose prefix moments are finalised together
+#define NACC 72
+#define PREFB 12        // calculations whose prefix moments are finalised together
+#define NHM 5           // half-mass weight classes: all, dark matter, gas, stars, baryons
 enum {
     A_N0 = 0, A_N1, A_N2, A_N3,        // counts per type slot
     A_M0 = 4, A_M1, A_M2, A_M3,        // mass per type slot
@@ -466,7 +468,12 @@ enum {
     A_MRS = 33,                        // sum m*max(r, softening)
     A_MSAT = 34, A_MEXT = 35,          // mass bound to satellites / external
     A_NFAR = 36,                       // members with r > 1e-8 (np.isclose(r, 0) false)
-    A_RMAX = 37                        // max r  (max-reduction)
+    A_RMAX = 37,                       // max r  (max-reduction)
+    // gas (type slot 0) and stars (type slot 2), only accumulated when the chunk has baryons:
+    // sum m*x (3), sum m*v' (3), sum m * x cross v' (3), sum m v'_a v'_b (6)
+    A_GMX = 38, A_GMV = 41, A_GL = 44, A_GVV = 47,
+    A_SMX = 53, A_SMV = 56, A_SL = 59, A_SVV = 62,
+    A_NSUM = 68                        // accumulators in use (the last slots of NACC are scratch)
 };
 
 #define GAS __attribute__((address_space(1)))
@@ -1080,6 +1087,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (calcs[c].kind == SOAP_CALC_SO_MULTIPLE) P.first_factor = std::max(P.first_factor, 0.86 * calcs[c].radius);
     }
     { const char *e = getenv("SOAP_ENGINE_PROFILE"); P.profile = e ? atoi(e) : 0; }
+    P.hydro = (h->t[0].n > 0 || h->t[2].n > 0) ? 1 : 0;
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;

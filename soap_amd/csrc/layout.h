@@ -11,7 +11,11 @@ enum {
     SH_HMR_tot = 22, SH_HMR_dm,
     SH_veldisp_dm = 24,
     SH_EncloseRadius = 30,
-    SH_NCOLS = 31
+    // gas / star / baryon kinematics (zero in dark-matter-only chunks)
+    SH_com_star = 31, SH_Lgas = 34, SH_Lstar = 37, SH_Lbaryons = 40,
+    SH_veldisp_gas = 43, SH_veldisp_star = 49,
+    SH_HMR_gas = 55, SH_HMR_star, SH_HMR_baryon,
+    SH_NCOLS = 58
 };
 // ---- SOAP_CALC_SO_* -------------------------------------------------------------
 enum {
@@ -24,7 +28,9 @@ enum {
     SOC_Ldm = 18,
     SOC_Mstar = 21, SOC_Mbh,
     SOC_spin = 23, SOC_conc_unsoft, SOC_conc_soft,
-    SOC_NCOLS = 26
+    SOC_com_gas = 26, SOC_com_star = 29, SOC_vcom_gas = 32, SOC_vcom_star = 35,
+    SOC_Lgas = 38, SOC_Lstar = 41, SOC_Lbaryons = 44,
+    SOC_NCOLS = 47
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {
@@ -33,7 +39,10 @@ enum {
     AP_com = 9, AP_vcom = 12, AP_Ldm = 15,
     AP_veldisp_dm = 18,
     AP_HMR_dm = 24, AP_Vmax_soft, AP_R_vmax_soft,
-    AP_NCOLS = 27
+    AP_com_star = 27, AP_vcom_star = 30, AP_Lgas = 33, AP_Lstar = 36, AP_Lbaryons = 39,
+    AP_veldisp_gas = 42, AP_veldisp_star = 48,
+    AP_HMR_gas = 54, AP_HMR_star, AP_HMR_baryon,
+    AP_NCOLS = 57
 };
 // ---- SOAP_CALC_PROJECTED: 3 blocks (projx, projy, projz) of PJ_NCOLS ---------------
 enum {
@@ -41,5 +50,7 @@ enum {
     PJ_Ngas, PJ_Ndm, PJ_Nstar, PJ_Nbh,
     PJ_com = 9, PJ_vcom = 12,
     PJ_HMR_dm = 15, PJ_veldisp_dm,
-    PJ_NCOLS = 17
+    PJ_com_star = 17, PJ_veldisp_gas = 20, PJ_veldisp_star,
+    PJ_HMR_gas = 22, PJ_HMR_star, PJ_HMR_baryon,
+    PJ_NCOLS = 25
 };

@@ -21,6 +21,9 @@ SUBHALO_COLS = {
     "Vmax_unsoft": (18, 1), "Vmax_soft": (19, 1), "R_vmax_unsoft": (20, 1), "spin_parameter": (21, 1),
     "HalfMassRadiusTot": (22, 1), "HalfMassRadiusDM": (23, 1),
     "veldisp_matrix_dm": (24, 6), "EncloseRadius": (30, 1),
+    "com_star": (31, 3), "Lgas": (34, 3), "Lstar": (37, 3), "Lbaryons": (40, 3),
+    "veldisp_matrix_gas": (43, 6), "veldisp_matrix_star": (49, 6),
+    "HalfMassRadiusGas": (55, 1), "HalfMassRadiusStar": (56, 1), "HalfMassRadiusBaryon": (57, 1),
 }  # fmt: skip
 SO_COLS = {
     "r": (0, 1), "Mtot": (1, 1), "Ngas": (2, 1), "Ndm": (3, 1), "Nstar": (4, 1), "Nbh": (5, 1),
@@ -28,27 +31,34 @@ SO_COLS = {
     "Mfrac_satellites": (14, 1), "Mfrac_external": (15, 1), "Mgas": (16, 1), "Mdm": (17, 1),
     "Ldm": (18, 3), "Mstar": (21, 1), "Mbh_dynamical": (22, 1), "spin_parameter": (23, 1),
     "concentration_unsoft": (24, 1), "concentration_soft": (25, 1),
+    "com_gas": (26, 3), "com_star": (29, 3), "vcom_gas": (32, 3), "vcom_star": (35, 3),
+    "Lgas": (38, 3), "Lstar": (41, 3), "Lbaryons": (44, 3),
 }  # fmt: skip
 APERTURE_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
     "Ngas": (5, 1), "Ndm": (6, 1), "Nstar": (7, 1), "Nbh": (8, 1),
     "com": (9, 3), "vcom": (12, 3), "Ldm": (15, 3), "veldisp_matrix_dm": (18, 6),
     "HalfMassRadiusDM": (24, 1), "Vmax_soft": (25, 1), "R_vmax_soft": (26, 1),
+    "com_star": (27, 3), "vcom_star": (30, 3), "Lgas": (33, 3), "Lstar": (36, 3), "Lbaryons": (39, 3),
+    "veldisp_matrix_gas": (42, 6), "veldisp_matrix_star": (48, 6),
+    "HalfMassRadiusGas": (54, 1), "HalfMassRadiusStar": (55, 1), "HalfMassRadiusBaryon": (56, 1),
 }  # fmt: skip
 PROJECTED_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
     "Ngas": (5, 1), "Ndm": (6, 1), "Nstar": (7, 1), "Nbh": (8, 1),
     "com": (9, 3), "vcom": (12, 3), "HalfMassRadiusDM": (15, 1), "proj_veldisp_dm": (16, 1),
+    "com_star": (17, 3), "proj_veldisp_gas": (20, 1), "proj_veldisp_star": (21, 1),
+    "HalfMassRadiusGas": (22, 1), "HalfMassRadiusStar": (23, 1), "HalfMassRadiusBaryon": (24, 1),
 }  # fmt: skip
-PROJECTED_NCOLS = 17
+PROJECTED_NCOLS = 25
 
 NCOLS = {
-    CALC_SUBHALO: 31,
-    CALC_SO_DENSITY: 26,
-    CALC_SO_PHYSICAL: 26,
-    CALC_SO_MULTIPLE: 26,
-    CALC_APERTURE_INCL: 27,
-    CALC_APERTURE_EXCL: 27,
+    CALC_SUBHALO: 58,
+    CALC_SO_DENSITY: 47,
+    CALC_SO_PHYSICAL: 47,
+    CALC_SO_MULTIPLE: 47,
+    CALC_APERTURE_INCL: 57,
+    CALC_APERTURE_EXCL: 57,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,
 }
 

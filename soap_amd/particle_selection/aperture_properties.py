@@ -21,6 +21,8 @@ class ApertureProperties(HaloProperty):
     property_names = [
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
+        "com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
+        "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, aperture_physical_radius_kpc, aperture_property,

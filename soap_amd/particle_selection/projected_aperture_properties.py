@@ -20,7 +20,9 @@ class ProjectedApertureProperties(HaloProperty):
     base_halo_type = "ProjectedApertureProperties"
     kind = layout.CALC_PROJECTED
     property_names = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
-                      "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm"]  # fmt: skip
+                      "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm",
+                      "com_star", "proj_veldisp_gas", "proj_veldisp_star",
+                      "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, aperture_physical_radius_kpc, aperture_property,
                  category_filter, halo_filter, all_radii_kpc):  # fmt: skip

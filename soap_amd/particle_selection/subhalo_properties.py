@@ -19,6 +19,8 @@ class SubhaloProperties(HaloProperty):
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "Vmax_unsoft", "Vmax_soft", "R_vmax_unsoft", "spin_parameter",
         "HalfMassRadiusTot", "HalfMassRadiusDM", "veldisp_matrix_dm", "EncloseRadius",
+        "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
+        "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters=None, recently_heated_gas_filter=None,

@@ -65,6 +65,21 @@ full_property_list = {
     "concentration_unsoft": Property("ConcentrationUnsoftened", 1, np.float32, "dimensionless", True, None, True, 0, "NFW concentration from the first radial moment (raw radii)."),
     "Mfrac_satellites": Property("MassFractionSatellites", 1, np.float32, "dimensionless", True, None, True, 0, "Mass fraction bound to satellites in the same FOF group."),
     "Mfrac_external": Property("MassFractionExternal", 1, np.float32, "dimensionless", True, None, True, 0, "Mass fraction bound to subhalos outside this FOF group."),
+    # gas / star / baryon kinematics (SOAP/property_table.py rows :1329-1448, :1541-1631, :3646-3669, :3856-3868, :4025-4073)
+    "com_gas": Property("GasCentreOfMass", 3, np.float64, _Lc, False, 1, False, 0, "Centre of mass of the gas."),
+    "com_star": Property("StellarCentreOfMass", 3, np.float64, _Lc, False, 1, False, 0, "Centre of mass of the stars."),
+    "vcom_gas": Property("GasCentreOfMassVelocity", 3, np.float32, _V, True, 0, False, 0, "Centre of mass velocity of the gas."),
+    "vcom_star": Property("StellarCentreOfMassVelocity", 3, np.float32, _V, True, 0, False, 0, "Centre of mass velocity of the stars."),
+    "Lgas": Property("AngularMomentumGas", 3, np.float32, _L, True, None, False, 1, "Angular momentum of the gas about the gas centre of mass velocity."),
+    "Lstar": Property("AngularMomentumStars", 3, np.float32, _L, True, None, False, 1, "Angular momentum of the stars about the stellar centre of mass velocity."),
+    "Lbaryons": Property("AngularMomentumBaryons", 3, np.float32, _L, True, None, False, 1, "Angular momentum of gas and stars about the baryonic centre of mass velocity."),
+    "veldisp_matrix_gas": Property("GasVelocityDispersionMatrix", 6, np.float32, _V2, True, 0, False, 0, "Mass-weighted velocity dispersion of the gas (XX YY ZZ XY XZ YZ)."),
+    "veldisp_matrix_star": Property("StellarVelocityDispersionMatrix", 6, np.float32, _V2, True, 0, False, 0, "Mass-weighted velocity dispersion of the stars (XX YY ZZ XY XZ YZ)."),
+    "proj_veldisp_gas": Property("GasProjectedVelocityDispersion", 1, np.float32, _V, True, 0, False, 0, "Gas velocity dispersion along the projection axis."),
+    "proj_veldisp_star": Property("StellarProjectedVelocityDispersion", 1, np.float32, _V, True, 0, False, 0, "Stellar velocity dispersion along the projection axis."),
+    "HalfMassRadiusGas": Property("HalfMassRadiusGas", 1, np.float32, _Lc, False, 1, False, 0, "Gas half mass radius."),
+    "HalfMassRadiusStar": Property("HalfMassRadiusStars", 1, np.float32, _Lc, False, 1, False, 0, "Stellar half mass radius."),
+    "HalfMassRadiusBaryon": Property("HalfMassRadiusBaryons", 1, np.float32, _Lc, False, 1, False, 0, "Baryonic (gas and stars) half mass radius."),
 }  # fmt: skip
 
 

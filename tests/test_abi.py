@@ -47,7 +47,8 @@ def test_layout_matches_library(built_library):
         assert np.all(used == 1), f"kind {kind}: columns overlap or have holes"
     # C header enum values the Python side relies on
     txt = open(os.path.join(ROOT, "soap_amd", "csrc", "layout.h")).read()
-    for name, val in (("SH_NCOLS", 31), ("SOC_NCOLS", 26), ("AP_NCOLS", 27), ("PJ_NCOLS", 17)):
+    for name, val in (("SH_NCOLS", layout.NCOLS[layout.CALC_SUBHALO]), ("SOC_NCOLS", layout.NCOLS[layout.CALC_SO_DENSITY]),
+                      ("AP_NCOLS", layout.NCOLS[layout.CALC_APERTURE_INCL]), ("PJ_NCOLS", layout.PROJECTED_NCOLS)):
         assert re.search(rf"{name}\s*=\s*{val}\b", txt)
 
 
