@@ -96,6 +96,33 @@ def stage_chunk(engine: Engine, data: Dict, resolution=None):
                                d["GroupNr_bound"], d["FOFGroupIDs"], res)  # fmt: skip
 
 
+class BatchResult:
+    """One engine run over a halo table, addressable by catalogue index: what the per-halo
+    `HaloProperty.calculate` facade reads (operator protocol)."""
+
+    STATUS_NEED_LARGER_READ_RADIUS = STATUS_NEED_LARGER_READ_RADIUS
+
+    def __init__(self, table, status, index, coloff, subhalo):
+        self.table, self.status, self.coloff, self.subhalo = table, status, coloff, subhalo
+        self._row = {int(ix): r for r, ix in enumerate(index)}
+
+    def row_of(self, index: int) -> int:
+        return self._row[index]
+
+
+def bind_results(engine: Engine, halo_prop_list: List, raw: Dict, halo_arrays: Dict) -> BatchResult:
+    """Make the result of `process_halos(..., unpack=...)` available to `prop.calculate(input_halo, ...)`
+    for every entry of halo_prop_list.  `raw` is the last element process_halos returned."""
+    calcs = [hp.calc_desc(halo_prop_list, i) for i, hp in enumerate(halo_prop_list)]
+    coloff = np.concatenate([[0], np.cumsum([engine._lib.soap_engine_calc_columns(c.kind) for c in calcs])])
+    table = raw["table"] if raw.get("table") is not None else engine.fetch(table=True)["table"]
+    index = np.asarray(halo_arrays["index"])[raw["rows"]]
+    batch = BatchResult(table, raw["status"], index, coloff, halo_prop_list[0])
+    for i, hp in enumerate(halo_prop_list):
+        hp.bind(batch, i)
+    return batch
+
+
 def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, results,
                   unpack: bool = True):  # fmt: skip
     """

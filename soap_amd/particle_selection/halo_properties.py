@@ -80,6 +80,40 @@ class HaloProperty:
             out.append(key)
         return out
 
+    # ---- the reference's per-halo operator protocol ------------------------------------------
+    def bind(self, batch, position: int):
+        """Attach the engine's batch result (soap_amd.core.halo_tasks.BatchResult) so that
+        `calculate` can serve single halos; `position` is this calculation's place in halo_prop_list."""
+        self._batch = batch
+        self._position = position
+
+    def calculate(self, input_halo: Dict, search_radius, data: Dict, halo_result: Dict) -> None:
+        """
+        Same signature and contract as HaloProperty.calculate of the reference
+        (particle_selection/SO_properties.py:3569-3742, aperture_properties.py:4024-4244, ...): ADD this
+        calculation's entries for `input_halo` to `halo_result`; raise SearchRadiusTooSmallError when
+        the halo needs a larger region; inputs are not modified.  Nothing is computed here -- the
+        values are the halo's row of the engine's batch result (the engine already ran the radius loop, so
+        `search_radius` and `data` are accepted for signature compatibility only).
+        """
+        batch = getattr(self, "_batch", None)
+        if batch is None:
+            raise RuntimeError("calculate() needs a batch result: call halo_tasks.bind_results first")
+        row = batch.row_of(int(input_halo["index"]))
+        status = int(batch.status[row])
+        if status == batch.STATUS_NEED_LARGER_READ_RADIUS:
+            raise SearchRadiusTooSmallError("the engine needs a larger read radius for this halo")
+        if status < 0:
+            raise RuntimeError(f"Object with HaloCatalogueIndex={int(input_halo['index'])} encountered an error")
+        block = batch.table[row, batch.coloff[self._position] : batch.coloff[self._position + 1]]
+        do_calc = None
+        if self._position > 0 and batch.subhalo is not None and batch.subhalo.category_filter is not None:
+            # property-level filters use the bound subhalo's particle counts (subhalo_properties.py:2618-2626)
+            tmp = {}
+            batch.subhalo.unpack(batch.table[row, batch.coloff[0] : batch.coloff[1]], tmp, None)
+            do_calc = batch.subhalo.category_filter.get_do_calculation(tmp)
+        self.unpack(block, halo_result, do_calc)
+
     # ---- result table -> halo_result --------------------------------------------------
     def unpack(self, block: np.ndarray, halo_result: Dict, do_calculation=None):
         """block: this calculation's columns of one halo row (fp64 raw values)."""

@@ -288,3 +288,39 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
     ngas = sum(int(helpers.engine_value(r, "BoundSubhalo", "Ngas")[0]) for r in results)
     assert ngas > 0
     engine.close()
+
+
+def test_per_halo_calculate_protocol(built_library):
+    """The reference's operator protocol: prop.calculate(input_halo, search_radius, data,
+    halo_result) ADDS '<group>/<PropertyName>' entries, leaves its inputs alone, and raises
+    SearchRadiusTooSmallError for a halo that needs a larger region -- served from the engine's batch run."""
+    from soap_amd.particle_selection.halo_properties import SearchRadiusTooSmallError
+
+    # read radii equal to the search radii and a 200-mean sphere: some halos need a larger region
+    sc, data, halos = make_chunk(60000, 40, seed=7, read_radius_factor=1.0)
+    data_np, halos_np = to_numpy(data, halos)
+    halos_np["read_radius"] = halos_np["read_radius"].copy()
+    halos_np["read_radius"][5:] *= 8.0          # ... but only the first five
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, {"200_mean": {"value": 200.0, "type": "mean"}},
+                                     chp.aperture_variations((50.0,)))  # fmt: skip
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    batch = halo_tasks.bind_results(engine, props, out[4], ha)
+    done_rows = np.flatnonzero(ha["done"] == 1)
+    assert 0 < len(done_rows) < len(ha["done"])
+    for j, row in enumerate(done_rows[:10]):
+        input_halo = {k: halos_np[k][row] for k in ("index", "cofp", "search_radius", "is_central", "nr_bound_part")}
+        before = {k: np.copy(v) for k, v in input_halo.items()}
+        halo_result = {}
+        for hp in props:
+            hp.calculate(input_halo, input_halo["search_radius"], data_np, halo_result)
+        for k, v in before.items():
+            assert np.array_equal(input_halo[k], v)   # inputs untouched (test_SO_properties.py:226-228)
+        want = {k: v for k, v in results[j].items() if not k.startswith("InputHalos/")}
+        assert set(halo_result) == set(want)
+        for k in want:
+            assert np.array_equal(halo_result[k][0], want[k][0]) and halo_result[k][0].dtype == want[k][0].dtype
+    todo_row = int(np.flatnonzero(ha["done"] == 0)[0])
+    with pytest.raises(SearchRadiusTooSmallError):
+        props[1].calculate({"index": halos_np["index"][todo_row]}, 0.0, data_np, {})
+    engine.close()
