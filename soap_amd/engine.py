@@ -47,6 +47,10 @@ def _ptr(x, dtype, shape_tail=()):
         import torch
 
         tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dtype]
+        if x.dtype == torch.float32 and tdt == torch.float64:
+            # real snapshots hold Velocities / Masses in float32: widened here, as
+            # np.ascontiguousarray does for host arrays below.  The engine's arithmetic is fp64 throughout.
+            x = x.to(torch.float64)
         if x.dtype != tdt:
             raise TypeError(f"expected torch dtype {tdt}, got {x.dtype}")
         if not x.is_contiguous():
@@ -86,6 +90,7 @@ class Engine:
         self._check(self._lib.soap_engine_create(C.byref(cfg), C.byref(self._h)))
         self.n_halo = 0
         self.calcs = []
+        self._staged = {}
 
     def _check(self, rc):
         if rc != 0:
@@ -129,6 +134,9 @@ class Engine:
                 1 if dev else 0,
             )  # fmt: skip
         )
+        # device-resident velocities / masses / ids are read in place until the next staging of this slot
+        # (include/soap_engine.h, lifetime rule): hold on to them (they may be widened / contiguous copies)
+        self._staged[int(type_slot)] = (k2, k3, k4, k5) if dev else None
 
     def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part):
         n = int(np.asarray(index).shape[0])

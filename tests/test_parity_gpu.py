@@ -324,3 +324,35 @@ def test_per_halo_calculate_protocol(built_library):
     with pytest.raises(SearchRadiusTooSmallError):
         props[1].calculate({"index": halos_np["index"][todo_row]}, 0.0, data_np, {})
     engine.close()
+
+
+def test_device_resident_float32_inputs(built_library):
+    """Real snapshots hold Velocities/Masses in float32 and the chunk may already live in HBM: device
+    tensors (float32 values widened on the device) must give exactly the table of the same values passed
+    as host float64 arrays."""
+    import torch
+
+    sc, data, halos = make_chunk(50000, 30, seed=17)
+    data_np, halos_np = to_numpy(data, halos)
+    for d in data_np.values():
+        d["Velocities"] = d["Velocities"].astype(np.float32).astype(np.float64)
+        d["Masses"] = d["Masses"].astype(np.float32).astype(np.float64)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}},
+                                     chp.aperture_variations((50.0,)))  # fmt: skip
+    e1, ha1, r1, o1 = _run_engine(sc, data_np, halos_np, props)
+    data_dev = {}
+    for pt, d in data_np.items():
+        data_dev[pt] = {
+            "Coordinates": torch.from_numpy(d["Coordinates"]).cuda(),
+            "Velocities": torch.from_numpy(d["Velocities"].astype(np.float32)).cuda(),
+            "Masses": torch.from_numpy(d["Masses"].astype(np.float32)).cuda(),
+            "GroupNr_bound": torch.from_numpy(d["GroupNr_bound"]).cuda(),
+            "FOFGroupIDs": torch.from_numpy(d["FOFGroupIDs"]).cuda(),
+        }
+    e2, ha2, r2, o2 = _run_engine(sc, data_dev, halos_np, props)
+    del data_dev   # the engine's Python side keeps what the kernels read in place
+    assert np.array_equal(o1[4]["status"], o2[4]["status"])
+    assert np.array_equal(o1[4]["table"], o2[4]["table"])
+    e1.close()
+    e2.close()
