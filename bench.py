@@ -136,9 +136,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # rehearsal knob (one-GPU boxes): BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo, to exercise
+    # the multi-rank code path without RCCL; the real launch is one rank per GPU over RCCL
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
 
@@ -161,22 +169,38 @@ def main():
     ncols_total = None
     gathered = None
 
+    # catalogue gather over xGMI: one all-gather of the (equal-sized) result tables per step.  Chunks are
+    # independent, so the gather of step k runs (async, on RCCL's stream, double-buffered) while step k+1
+    # stages and processes its chunk; every gather is complete before the timed region ends (sync()).
+    pending = [None, None]
+    bufs = [None, None]
+    k_step = 0
+
     def step():
-        nonlocal ncols_total, gathered
+        nonlocal ncols_total, gathered, k_step
         halo_tasks.stage_chunk(engine, data)
         ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
         out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
         raw = out[4]
         if world > 1:
-            # catalogue gather over xGMI: one all-gather of the (equal-sized) result tables
             nc = engine.row_columns
-            mine = torch.empty(H * nc, dtype=torch.float64, device=f"cuda:{local_rank}")
-            engine.copy_table_to(mine)
-            gathered = torch.empty(world * H * nc, dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_gather_into_tensor(gathered, mine)
+            b = k_step % 2
+            if pending[b] is not None:
+                pending[b].wait()
+            if bufs[b] is None:
+                bufs[b] = (torch.empty(H * nc, dtype=torch.float64, device=f"cuda:{local_rank}"),
+                           torch.empty(world * H * nc, dtype=torch.float64, device=f"cuda:{local_rank}"))
+            engine.copy_table_to(bufs[b][0])
+            pending[b] = dist.all_gather_into_tensor(bufs[b][1], bufs[b][0], async_op=True)
+            gathered = bufs[b][1]
+            k_step += 1
         return raw, out[2]
 
     def sync():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
