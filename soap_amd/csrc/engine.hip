@@ -316,25 +316,40 @@ __global__ void k_minmax(const double *pos, long long n, double *partial /*[grid
 // counter[key] += 1 for every active lane, returning the value each lane would have got from its own
 // atomicAdd.  Snapshot particles arrive spatially coherent (halo by halo / cell by cell), so most lanes
 // of a wavefront hit the same counter: lanes with equal keys are merged into one atomic (up to 4 distinct
-// keys per wavefront; whatever is left falls back to one atomic per lane).
+// keys per wavefront; whatever is left adds 1 per lane).  The groups are found first (ballots only); then
+// ONE atomic instruction is issued by the group leaders and the leftover lanes together, so the wave pays a
+// single L2 round trip per call (and none at all when the result is not used: the histogram pass).
+// (Tried and dropped: per-thread runs over 8 consecutive particles to cut same-address atomics further --
+// the strided AoS reads cost more than the atomics saved, 9.8 ms instead of 6.2 ms for 10^8 particles.)
+template <bool WANT_RESULT>
 __device__ __forceinline__ unsigned wave_agg_inc(unsigned *counter, unsigned key, bool active) {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(active);
-    unsigned res = 0;
     bool mine = active;
+    int my_leader = -1, my_rank = 0, my_cnt = 0;
     for (int round = 0; round < 4 && todo; round++) {
         const int leader = __ffsll((long long)todo) - 1;
-        const unsigned k0 = __shfl(key, leader, 64);
+        const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
         const bool in = mine && key == k0;
         const unsigned long long grp = __ballot(in);
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&counter[k0], (unsigned)__popcll(grp));
-        base = __shfl(base, leader, 64);
-        if (in) { res = base + (unsigned)__popcll(grp & ((1ull << lane) - 1ull)); mine = false; }
+        if (in) {
+            my_leader = leader;
+            my_rank = __popcll(grp & ((1ull << lane) - 1ull));
+            my_cnt = __popcll(grp);
+            mine = false;
+        }
         todo &= ~grp;
     }
-    if (mine) res = atomicAdd(&counter[key], 1u);
-    return res;
+    const bool is_leader = my_leader == lane;
+    unsigned base = 0;
+    if (is_leader || mine) {
+        const unsigned addv = is_leader ? (unsigned)my_cnt : 1u;
+        if (WANT_RESULT) base = atomicAdd(&counter[key], addv);
+        else (void)atomicAdd(&counter[key], addv);
+    }
+    if (!WANT_RESULT) return 0u;
+    const unsigned lb = (unsigned)__shfl((int)base, my_leader >= 0 ? my_leader : lane, 64);
+    return my_leader >= 0 ? lb + (unsigned)my_rank : base;
 }
 
 struct MeshGeom {
@@ -359,7 +374,7 @@ __global__ void k_cellid(const double *pos, long long n, MeshGeom g, unsigned *c
         unsigned id = (unsigned)c[0] + (unsigned)g.res * (unsigned)c[1] +
                       (unsigned)g.res * (unsigned)g.res * (unsigned)c[2];
         cell[i] = id;
-        (void)wave_agg_inc(count, id, true);
+        (void)wave_agg_inc<false>(count, id, true);
     }
 }
 
@@ -430,7 +445,7 @@ __global__ void k_scatter(const unsigned *cell, long long n, const unsigned *off
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
          i += (long long)gridDim.x * BLK) {
         unsigned c = cell[i];
-        unsigned r = wave_agg_inc(cursor, c, true);
+        unsigned r = wave_agg_inc<true>(cursor, c, true);
         sort_idx[offset[c] + r] = (unsigned)i;
     }
 }
