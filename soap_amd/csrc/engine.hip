@@ -108,6 +108,7 @@ struct RunParams {
     double first_factor;   // first sorted superset reaches first_factor * search_radius
     int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
     int hydro;             // gas or star particles staged: the baryon kinematics are computed
+    int dm_only;           // only dark matter staged
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -1103,6 +1104,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     }
     { const char *e = getenv("SOAP_ENGINE_PROFILE"); P.profile = e ? atoi(e) : 0; }
     P.hydro = (h->t[0].n > 0 || h->t[2].n > 0) ? 1 : 0;
+    P.dm_only = (h->t[0].n == 0 && h->t[2].n == 0 && h->t[3].n == 0) ? 1 : 0;
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
