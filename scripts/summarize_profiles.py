@@ -7,7 +7,11 @@ DST = sys.argv[2] if len(sys.argv) > 2 else "profiles/round1"
 TAG = sys.argv[3] if len(sys.argv) > 3 else "final"
 os.makedirs(DST, exist_ok=True)
 
-stats = glob.glob(f"{SRC}/stats/*/*kernel_stats.csv")[0]
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(f"{SRC}/stats/*/*kernel_stats.csv")
 shutil.copy(stats, f"{DST}/{TAG}_c3_kernel_stats.csv")
 dur = {}
 for row in csv.DictReader(open(stats)):
@@ -15,7 +19,7 @@ for row in csv.DictReader(open(stats)):
         dur[row["Name"].split("(")[0]] = float(row["AverageNs"]) * 1e-6
 
 def pmc(name, counter):
-    f = glob.glob(f"{SRC}/{name}/*/*counter_collection.csv")[0]
+    f = newest(f"{SRC}/{name}/*/*counter_collection.csv")
     agg = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] == counter and "k_halo" in row["Kernel_Name"]:
@@ -39,5 +43,6 @@ out["traffic_bytes_per_step_raw"] = raw
 out["traffic_bytes_per_step_corrected"] = cor
 out["algorithmic_bytes_per_step"] = line["roofline"]["algorithmic_bytes"]
 json.dump(out, open(f"{DST}/{TAG}_c3_hbm_traffic.json", "w"), indent=1)
+line["roofline"]["traffic"] = cor   # the value measured in THIS profile set (bench.py quotes the committed one)
 json.dump(line, open(f"{DST}/{TAG}_c3_bench.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
