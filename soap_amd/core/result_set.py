@@ -1,0 +1,158 @@
+"""
+Column store of finished halos and the chunk loop that fills it: the counterpart of
+`ResultSet` (SOAP/core/result_set.py:74-130), the per-chunk part of `ChunkTask.__call__`
+(SOAP/core/chunk_tasks.py:284-340) and the ordering rule of `combine_chunks`
+(SOAP/core/combine_chunks.py:38-52).
+
+The reference appends one dictionary per halo and concatenates at the end.  Here the engine hands back a
+dense fp64 table, so the columns are cut out of it for all halos at once: one cast per property to the
+dtype of `property_table.py`, property-level category filters applied as row masks, datasets named
+`"<group>/<PropertyName>"` exactly as the reference names them
+(`SO/200_crit/SORadius`, `InclusiveSphere/50kpc/TotalMass`, `ProjectedAperture/30kpc/projx/...`,
+`BoundSubhalo/...`, `InputHalos/...`).
+"""
+
+from __future__ import annotations
+
+import json
+from typing import Dict, List
+
+import numpy as np
+
+from .. import layout
+from ..property_table import full_property_list
+
+from .halo_tasks import _INPUT_HALO_COLUMNS   # InputHalos/* datasets every catalogue carries
+
+
+class ResultSet:
+    """Named, typed columns of the halos finished so far (any number of `append_table` calls)."""
+
+    def __init__(self, halo_prop_list: List, engine_calc_columns):
+        self.props = list(halo_prop_list)
+        ncols = [int(engine_calc_columns(hp.kind)) for hp in self.props]
+        self.coloff = np.concatenate([[0], np.cumsum(ncols)]).astype(np.int64)
+        self._chunks: Dict[str, List[np.ndarray]] = {}
+        self.meta: Dict[str, Dict] = {}
+        self.n_halo = 0
+
+    # -- filling ------------------------------------------------------------------------------
+    def append_table(self, table: np.ndarray, halo_arrays: Dict[str, np.ndarray]) -> None:
+        """table: fp64 rows of finished halos (engine layout); halo_arrays: the same halos' catalogue
+        columns (index, cofp, is_central, nr_bound_part)."""
+        n = table.shape[0]
+        if n == 0:
+            return
+        do_calc = self._row_filters(table)
+        for ci, hp in enumerate(self.props):
+            block = table[:, self.coloff[ci] : self.coloff[ci + 1]]
+            cols = layout.columns_of(hp.kind)
+            for proj, base in _projections(hp):
+                for key in hp.enabled_properties():
+                    prop = full_property_list[key]
+                    c0, nc = cols[key]
+                    raw = block[:, base + c0 : base + c0 + nc]
+                    filt = hp.property_filters.get(prop.name, "basic")
+                    if ci > 0 and filt != "basic" and filt in do_calc:   # the subhalo itself is never filtered
+                        raw = np.where(do_calc[filt][:, None], raw, 0.0)
+                    name = f"{hp.group_name}{proj}/{prop.name}"
+                    self._put(name, _cast(raw, prop, hp.a), prop.unit, prop.description,
+                              prop.output_physical, prop.a_scale_exponent)  # fmt: skip
+        for src, (name, dtype, desc, phys, aexp) in _INPUT_HALO_COLUMNS.items():
+            unit = "snap_length" if src == "cofp" else "dimensionless"
+            self._put(name, np.asarray(halo_arrays[src]).astype(dtype), unit, desc, phys, aexp)
+        self.n_halo += n
+
+    def _row_filters(self, table):
+        """Property-level category filters, vectorised: the bound subhalo's particle counts per halo
+        (subhalo_properties.py:2618-2626, category_filter.py:69-106)."""
+        sub = self.props[0]
+        cf = getattr(sub, "category_filter", None)
+        if cf is None:
+            return {}
+        cols = layout.columns_of(sub.kind)
+        blk = table[:, self.coloff[0] : self.coloff[1]]
+        counts = {s: blk[:, cols[k][0]].astype(np.int64) for s, k in ((0, "Ngas"), (1, "Ndm"), (2, "Nstar"), (3, "Nbh"))}
+        out = {}
+        for fname in cf.filters:
+            limit, mask = cf.engine_filter(fname)
+            v = np.zeros(table.shape[0], dtype=np.int64)
+            for s in range(4):
+                if mask & (1 << s):
+                    v += counts[s]
+            out[fname] = v >= limit
+        return out
+
+    def _put(self, name, values, unit, desc, physical, a_exp):
+        self._chunks.setdefault(name, []).append(values)
+        self.meta.setdefault(name, {"unit": unit, "description": desc, "output_physical": bool(physical),
+                                    "a_scale_exponent": a_exp, "dtype": str(values.dtype)})  # fmt: skip
+
+    # -- reading ------------------------------------------------------------------------------
+    def columns(self) -> Dict[str, np.ndarray]:
+        return {k: np.concatenate(v, axis=0) for k, v in self._chunks.items()}
+
+    def sorted_columns(self, cell_size, dimension) -> Dict[str, np.ndarray]:
+        """Final catalogue order: SWIFT cell of the halo centre, then catalogue index
+        (combine_chunks.py:38-52)."""
+        from ..catalogue import spatial_sort_order
+
+        cols = self.columns()
+        order = spatial_sort_order(cols["InputHalos/HaloCentre"], cols["InputHalos/HaloCatalogueIndex"], cell_size, dimension)
+        return {k: v[order] for k, v in cols.items()}
+
+    def write(self, path: str, cell_size=None, dimension=None) -> None:
+        """`path`.npz with one array per dataset and `path`.json with unit / description / physical /
+        a-exponent per dataset (h5py is not available in this environment; the names and dtypes are the
+        reference's, so a converter to the SOAP HDF5 layout is a loop over the keys)."""
+        cols = self.sorted_columns(cell_size, dimension) if cell_size is not None else self.columns()
+        np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in cols.items()})
+        with open(path + ".json", "w") as f:
+            json.dump(self.meta, f, indent=1, sort_keys=True)
+
+
+def _projections(hp):
+    """('', 0) for ordinary calculations; ('/projx', 0), ('/projy', NC), ('/projz', 2 NC) for projected apertures
+    (projected_aperture_properties.py:1891-1999: one group per projection axis)."""
+    if hp.kind == layout.CALC_PROJECTED:
+        return [(f"/{p}", i * layout.PROJECTED_NCOLS) for i, p in enumerate(("projx", "projy", "projz"))]
+    return [("", 0)]
+
+
+def _cast(raw, prop, a):
+    """One cast to the table dtype, the way the reference fills a zero-initialised array of that dtype
+    (SO_properties.py:3600-3620, :3682-3699)."""
+    raw = np.asarray(raw, dtype=np.float64)
+    if np.issubdtype(prop.dtype, np.integer):
+        out = raw.astype(prop.dtype)
+    else:
+        out = np.zeros(raw.shape, dtype=prop.dtype)
+        out += raw * (a**prop.a_power) if prop.a_power else raw
+    return out[:, 0] if prop.shape == 1 else out
+
+
+def run_chunk(engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, max_passes: int = 8) -> ResultSet:
+    """
+    Process every halo of a staged chunk: repeat `process_halos` while halos ask for a larger read radius
+    (chunk_tasks.py:306-340: the reference re-reads a larger region and calls process_halos again; here
+    the chunk's particles are already resident, so a pass just re-runs the unfinished halos with the radii
+    the engine returned).  Returns the ResultSet of all finished halos; `halo_arrays["done"]` tells which.
+    """
+    from . import halo_tasks
+
+    rs = ResultSet(halo_prop_list, engine._lib.soap_engine_calc_columns)
+    halo_arrays.setdefault("done", np.zeros(len(halo_arrays["index"]), dtype=np.int32))
+    for _ in range(max_passes):
+        if not np.any(halo_arrays["done"] == 0):
+            break
+        before = int(np.sum(halo_arrays["done"]))
+        out = halo_tasks.process_halos(engine, halo_prop_list, cellgrid, halo_arrays, None, unpack=False)
+        raw = out[4]
+        ok = raw["status"] == halo_tasks.STATUS_OK
+        rows = raw["rows"][ok]
+        if rows.size:
+            table = engine.fetch(table=True)["table"][ok]
+            rs.append_table(table, {k: np.asarray(halo_arrays[k])[rows] for k in _INPUT_HALO_COLUMNS})
+        if int(np.sum(halo_arrays["done"])) == before and not np.any(raw["status"] == halo_tasks.STATUS_NEED_LARGER_READ_RADIUS):
+            break
+    return rs

@@ -109,3 +109,42 @@ def test_synthetic_chunk_is_self_consistent():
     for c in h["cofp"][:5]:
         assert np.any(np.all(pos == c, axis=1))
     assert pos.min() >= 0 and pos.max() < sc.boxsize
+
+
+def test_result_set_columns_from_a_table():
+    """ResultSet cuts named, typed columns out of an engine-layout table without a GPU: dataset names per
+    group (and per projection), one cast per property, property filters as row masks driven by the bound
+    subhalo's counts."""
+    from soap_amd import compute_halo_properties as chp
+    from soap_amd import layout
+    from soap_amd.core.category_filter import CategoryFilter
+    from soap_amd.core.result_set import ResultSet
+    from soap_amd.units import SnapshotScalars
+
+    sc = SnapshotScalars()
+    cf = CategoryFilter(dmo=False)
+    props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}},
+                                     chp.aperture_variations((50.0,)), projected_vars=chp.projected_variations((30.0,)))  # fmt: skip
+    rs = ResultSet(props, lambda kind: layout.NCOLS[kind])
+    n = 7
+    rng = np.random.default_rng(3)
+    table = rng.uniform(1.0, 2.0, size=(n, int(rs.coloff[-1])))
+    sub = layout.SUBHALO_COLS
+    table[:, sub["Ngas"][0]] = [0, 150, 0, 99, 100, 5, 300]
+    table[:, sub["Ndm"][0]] = 1000
+    table[:, sub["Nstar"][0]] = 0
+    table[:, sub["Nbh"][0]] = 0
+    ha = {"index": np.arange(n) + 10, "cofp": rng.uniform(0, 1, (n, 3)), "is_central": np.ones(n, dtype=np.int32),
+          "nr_bound_part": np.full(n, 1000)}  # fmt: skip
+    rs.append_table(table, ha)
+    cols = rs.columns()
+    assert cols["SO/200_crit/SORadius"].dtype == np.float32 and cols["SO/200_crit/SORadius"].shape == (n,)
+    assert cols["BoundSubhalo/CentreOfMass"].dtype == np.float64 and cols["BoundSubhalo/CentreOfMass"].shape == (n, 3)
+    assert cols["BoundSubhalo/NumberOfGasParticles"].dtype == np.uint32
+    assert "ProjectedAperture/30kpc/projy/TotalMass" in cols
+    assert np.array_equal(cols["InputHalos/HaloCatalogueIndex"], ha["index"])
+    # every property of every calculation, per projection for the projected apertures
+    want = sum(len(hp.enabled_properties()) * (3 if hp.kind == layout.CALC_PROJECTED else 1) for hp in props) + 4
+    assert len(cols) == want
+    # the first column of the table is BoundSubhalo/TotalMass, stored as float32
+    assert np.array_equal(cols["BoundSubhalo/TotalMass"], table[:, 0].astype(np.float32))

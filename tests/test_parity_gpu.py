@@ -356,3 +356,50 @@ def test_device_resident_float32_inputs(built_library):
     assert np.array_equal(o1[4]["table"], o2[4]["table"])
     e1.close()
     e2.close()
+
+
+def test_chunk_harness_columns_match_per_halo_results(built_library, tmp_path):
+    """run_chunk + ResultSet (the counterpart of ChunkTask / ResultSet / combine_chunks ordering): the
+    vectorised columns must be exactly what the per-halo dictionaries hold, halos that needed a larger read
+    radius are finished by a later pass, and the written catalogue is in (cell, catalogue index) order."""
+    from soap_amd.core.result_set import run_chunk
+
+    sc, data, halos = make_chunk(80000, 60, seed=9, read_radius_factor=1.0, hydro=True)
+    data_np, halos_np = to_numpy(data, halos)
+    halos_np["read_radius"] = halos_np["read_radius"].copy()
+    halos_np["read_radius"][10:] *= 8.0
+    cf = CategoryFilter(dmo=False)
+    so_vars = {"200_mean": {"value": 200.0, "type": "mean"}}
+    props = chp.build_halo_prop_list(sc, cf, so_vars, chp.aperture_variations((50.0,)),
+                                     projected_vars=chp.projected_variations((30.0,)))  # fmt: skip
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha = {k: v.copy() for k, v in halos_np.items()}
+    rs = run_chunk(engine, props, sc, ha)
+    assert np.all(ha["done"] == 1) and rs.n_halo == len(ha["index"])
+    # reference path: per-halo dictionaries, same passes
+    ha2 = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(len(halos_np["index"]), dtype=np.int32))
+    results = []
+    for _ in range(8):
+        if not np.any(ha2["done"] == 0):
+            break
+        halo_tasks.process_halos(engine, props, sc, ha2, results)
+    cols = rs.columns()
+    by_index = {int(r["InputHalos/HaloCatalogueIndex"][0]): r for r in results}
+    assert len(by_index) == rs.n_halo
+    for row, ix in enumerate(cols["InputHalos/HaloCatalogueIndex"]):
+        r = by_index[int(ix)]
+        assert set(r) == set(cols)
+        for name, val in r.items():
+            got = np.atleast_1d(cols[name][row])
+            assert got.dtype == np.asarray(val[0]).dtype, name
+            assert np.array_equal(got, np.atleast_1d(val[0])), name
+    # writer: sorted by (cell, index), names and dtypes as the reference's datasets
+    cell = sc.boxsize / 4.0
+    rs.write(str(tmp_path / "cat"), cell_size=[cell] * 3, dimension=[4, 4, 4])
+    z = np.load(str(tmp_path / "cat.npz"))
+    assert "SO|200_mean|SORadius" in z.files and z["SO|200_mean|SORadius"].dtype == np.float32
+    ci = (z["InputHalos|HaloCentre"] // cell).astype(np.int64)
+    key = ci[:, 0] * 16 + ci[:, 1] * 4 + ci[:, 2]
+    assert np.all(np.diff(key) >= 0)
+    engine.close()
