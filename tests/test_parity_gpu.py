@@ -403,3 +403,21 @@ def test_chunk_harness_columns_match_per_halo_results(built_library, tmp_path):
     key = ci[:, 0] * 16 + ci[:, 1] * 4 + ci[:, 2]
     assert np.all(np.diff(key) >= 0)
     engine.close()
+
+
+def test_many_calculations_per_family(built_library):
+    """More calculations in one family than the engine finalises in one batch (PREFB = 12): the nine default
+    SO definitions plus five inclusive spheres = 14 nested selections over all particles, 1 + 5 over the
+    bound ones; 20 calculations in total (the engine limit is 32)."""
+    sc, data, halos = make_chunk(90000, 50, seed=29)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    ap_vars = chp.aperture_variations((10.0, 30.0, 50.0, 100.0, 300.0))
+    props = chp.build_halo_prop_list(sc, cf, None, ap_vars)
+    assert 20 <= len(props) <= 32
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, None, ap_vars)
+    assert np.array_equal(ha["done"], ha_ref["done"]) and ha["done"].sum() > 10
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        compare_halo(ref[row], results[j], sc)
+    engine.close()
