@@ -1076,7 +1076,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
 
     long long ntot = 0;
     for (int t = 0; t < SOAP_NTYPES; t++) ntot += h->t[t].n;
-    const long long cap_max = next_pow2(std::max<long long>(ntot, 64));
+    // room for every staged particle plus the power-of-two padding of the fallback sort of an appended shell
+    const long long cap_max = 2 * next_pow2(std::max<long long>(ntot, 64));
 
     RunParams P;
     memset(&P, 0, sizeof(P));

@@ -421,3 +421,73 @@ def test_many_calculations_per_family(built_library):
     for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
         compare_halo(ref[row], results[j], sc)
     engine.close()
+
+
+def _tiny_periodic_chunk(L=2.0, n=6000, centres=((0.05, 0.1, 1.95), (1.0, 1.0, 1.0)), rb=0.25, seed=0):
+    """Uniform particles in a box so small that search spheres are larger than half the box: the ball query
+    needs several periodic copies per dimension (shared_mesh.py:146-179)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0.0, L, size=(n, 3))
+    vel = rng.normal(0.0, 100.0, size=(n, 3))
+    mass = np.full(n, 1.0e-2)
+    grnr = np.full(n, -1, dtype=np.int32)
+    index = []
+    for h, c in enumerate(centres):
+        d = pos - np.asarray(c)
+        d -= L * np.round(d / L)
+        r = np.sqrt((d**2).sum(axis=1))
+        sel = (r < rb) & (grnr < 0)
+        grnr[sel] = 7 + h
+        index.append(7 + h)
+    data = {1: {"Coordinates": pos, "Velocities": vel, "Masses": mass, "GroupNr_bound": grnr,
+                "FOFGroupIDs": np.where(grnr >= 0, 1, 2147483647).astype(np.int64)}}  # fmt: skip
+    nb = np.array([(grnr == ix).sum() for ix in index], dtype=np.int64)
+    halos = {"index": np.array(index, dtype=np.int64), "cofp": np.array(centres, dtype=np.float64),
+             "search_radius": np.full(len(index), 0.3), "read_radius": np.full(len(index), 1.9),
+             "is_central": np.ones(len(index), dtype=np.int32), "nr_bound_part": nb}  # fmt: skip
+    return data, halos
+
+
+def test_periodic_copies_in_a_tiny_box(built_library):
+    import dataclasses
+
+    from soap_amd.units import SnapshotScalars
+
+    sc = dataclasses.replace(SnapshotScalars(), boxsize=2.0)
+    data_np, halos_np = _tiny_periodic_chunk(L=sc.boxsize)
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_mean": {"value": 200.0, "type": "mean"}}
+    ap_vars = chp.aperture_variations((100.0, 1000.0))
+    props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars)
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, ap_vars)
+    assert np.array_equal(ha["done"], ha_ref["done"])
+    assert np.array_equal(ha["read_radius"], ha_ref["read_radius"]) and np.array_equal(ha["search_radius"], ha_ref["search_radius"])
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        compare_halo(ref[row], results[j], sc)
+    engine.close()
+
+
+def test_fatal_and_empty_cases(built_library):
+    """'Found more particles than expected' aborts the chunk with the reference's message
+    (subhalo_properties.py:2642-2646, halo_tasks.py:140-146); an empty halo table and an absent particle
+    type are fine (SharedMesh.empty, shared_mesh.py:25-27)."""
+    sc, data, halos = make_chunk(40000, 20, seed=41)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}}, {})
+    engine = halo_tasks.make_engine(sc, device=0)
+    empty = {k: v[:0] for k, v in data_np[1].items()}
+    halo_tasks.stage_chunk(engine, {1: data_np[1], 0: empty})
+    # no halos at all
+    ha0 = dict({k: v[:0].copy() for k, v in halos_np.items()}, done=np.zeros(0, dtype=np.int32))
+    res0 = []
+    out0 = halo_tasks.process_halos(engine, props, sc, ha0, res0)
+    assert res0 == [] and out0[2] == 0 and out0[3] == 0
+    # one halo claims fewer bound particles than it has
+    bad = {k: v.copy() for k, v in halos_np.items()}
+    bad["nr_bound_part"][3] -= 1
+    ha = dict(bad, done=np.zeros(len(bad["index"]), dtype=np.int32))
+    with pytest.raises(RuntimeError, match="more particles than expected"):
+        halo_tasks.process_halos(engine, props, sc, ha, [])
+    engine.close()
