@@ -491,3 +491,102 @@ def test_fatal_and_empty_cases(built_library):
     with pytest.raises(RuntimeError, match="more particles than expected"):
         halo_tasks.process_halos(engine, props, sc, ha, [])
     engine.close()
+
+
+def _dummy_generator_style_chunk(mean_density, nhalo=100, seed=4251, spacing=8.0):
+    """Halos in the style of the reference's test generator (tests/dummy_halo_generator.py:751-1423, as
+    summarised in SURVEY.md section 4): exponential radii with scale 1/60 Mpc around a first particle at r = 0,
+    masses U[0.1, 0.5], velocities U[-500, 500], types gas/DM/star/BH with p = (0.2, 0.4, 0.39, 0.01), 60 % of the
+    particles bound to the halo, ~10 % unbound, the rest bound to other objects (1 % satellites of the same FOF
+    group).  One isolated halo per lattice site, so every halo sees only its own particles -- the situation
+    of the reference's per-halo unit tests."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(nhalo ** (1.0 / 3.0)))
+    L = spacing * side
+    parts = {t: {"Coordinates": [], "Velocities": [], "Masses": [], "GroupNr_bound": [], "FOFGroupIDs": []} for t in (0, 1, 4, 5)}
+    halos = {"index": [], "cofp": [], "search_radius": [], "read_radius": [], "is_central": [], "nr_bound_part": []}
+    for h in range(nhalo):
+        centre = (np.array([h % side, (h // side) % side, h // (side * side)], dtype=np.float64) + 0.5) * spacing
+        centre += rng.uniform(-0.3, 0.3, 3)
+        n = int(rng.choice([1, 10, 100, 400, 1500]))
+        r = rng.exponential(1.0 / 60.0, n)
+        r[0] = 0.0
+        phi, ct = rng.uniform(0, 2 * np.pi, n), rng.uniform(-1, 1, n)
+        st = np.sqrt(1 - ct * ct)
+        pos = centre + r[:, None] * np.stack([st * np.cos(phi), st * np.sin(phi), ct], axis=1)
+        pos %= L
+        vel = rng.uniform(-500.0, 500.0, (n, 3))
+        mass = rng.uniform(0.1, 0.5, n)
+        types = rng.choice([0, 1, 4, 5], size=n, p=[0.2, 0.4, 0.39, 0.01])
+        index = 1000 + 3 * h
+        u = rng.uniform(0, 1, n)
+        grnr = np.where(u < 0.6, index, np.where(u < 0.7, -1, np.where(u < 0.71, index + 1, index + 2))).astype(np.int32)
+        grnr[0] = index
+        fof = np.where(grnr == index + 2, 500000 + h, np.where(grnr >= 0, 7000 + h, 2147483647)).astype(np.int64)
+        for t in (0, 1, 4, 5):
+            m = types == t
+            parts[t]["Coordinates"].append(pos[m]); parts[t]["Velocities"].append(vel[m]); parts[t]["Masses"].append(mass[m])
+            parts[t]["GroupNr_bound"].append(grnr[m]); parts[t]["FOFGroupIDs"].append(fof[m])
+        halos["index"].append(index); halos["cofp"].append(centre % L)
+        halos["search_radius"].append(0.05); halos["read_radius"].append(3.9)
+        halos["is_central"].append(1 if rng.uniform() < 0.9 else 0)
+        halos["nr_bound_part"].append(int((grnr == index).sum()))
+    # a smooth dark-matter background at the mean density: without it an isolated blob has no SO radius at all
+    # (the enclosed density never drops below the threshold at a particle)
+    nbg = 60000
+    parts[1]["Coordinates"].append(rng.uniform(0.0, L, (nbg, 3)))
+    parts[1]["Velocities"].append(rng.uniform(-500.0, 500.0, (nbg, 3)))
+    parts[1]["Masses"].append(np.full(nbg, mean_density * L**3 / nbg))
+    parts[1]["GroupNr_bound"].append(np.full(nbg, -1, dtype=np.int32))
+    parts[1]["FOFGroupIDs"].append(np.full(nbg, 2147483647, dtype=np.int64))
+    data = {t: {k: np.concatenate(v) if len(v) else np.zeros(0) for k, v in d.items()} for t, d in parts.items()}
+    hal = {"index": np.array(halos["index"], dtype=np.int64), "cofp": np.array(halos["cofp"]),
+           "search_radius": np.array(halos["search_radius"]), "read_radius": np.array(halos["read_radius"]),
+           "is_central": np.array(halos["is_central"], dtype=np.int32),
+           "nr_bound_part": np.array(halos["nr_bound_part"], dtype=np.int64)}  # fmt: skip
+    order = np.argsort(-hal["nr_bound_part"], kind="stable")
+    return L, data, {k: v[order] for k, v in hal.items()}
+
+
+def test_reference_style_random_halos(built_library):
+    """The reference's own unit tests push ~100 random multi-type halos through every SO flavour, a radius
+    multiple, spheres and projected apertures (tests/test_SO_properties.py:16-376 and friends) and check
+    presence / dtype / zeros for filtered halos.  Same population here, checked value by value against the
+    oracle, plus those schema checks."""
+    import dataclasses
+
+    from soap_amd.units import SnapshotScalars
+
+    sc0 = SnapshotScalars()
+    L, data_np, halos_np = _dummy_generator_style_chunk(sc0.mean_density * sc0.a**3)
+    sc = dataclasses.replace(sc0, boxsize=L)
+    cf = CategoryFilter(dmo=False)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "200_mean": {"value": 200.0, "type": "mean"},
+               "BN98": {"value": 0.0, "type": "BN98"}, "500_crit": {"value": 500.0, "type": "crit"},
+               "5xR_500_crit": {"value": 500.0, "type": "crit", "radius_multiple": 5.0}}  # fmt: skip
+    ap_vars = chp.aperture_variations((30.0, 50.0))
+    pj_vars = chp.projected_variations((30.0,))
+    props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars)
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, ap_vars, projected_vars=pj_vars)
+    assert np.array_equal(ha["done"], ha_ref["done"]) and ha["done"].sum() > 60
+    nzero_filtered = 0
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        o, hr = ref[row], results[j]
+        for okey, val in o.items():
+            group, key = okey.rsplit("/", 1)
+            prop = full_property_list[key]
+            got_stored = hr[f"{group}/{prop.name}"][0]
+            assert got_stored.dtype == prop.dtype and got_stored.shape == (prop.shape,)   # test_SO_properties.py:230-241
+            got, want = helpers.engine_value(hr, group, key), val.raw
+            if key in ("Ndm", "Ngas", "Nstar", "Nbh"):
+                assert np.array_equal(got, want), f"{okey}: {got} != {want}"
+            else:
+                M, vscale = _scales(o, group)
+                helpers.assert_close(okey, got, want, rtol=1e-10, scale=_abs_scale(key, M, vscale), atol_factor=1e-12)
+        # satellites get no SO (SO_properties.py:3600-3627): all zero
+        if halos_np["is_central"][row] == 0:
+            assert all(np.all(v[0] == 0) for k, v in hr.items() if k.startswith("SO/"))
+            nzero_filtered += 1
+    assert nzero_filtered > 0
+    engine.close()
