@@ -590,3 +590,52 @@ def test_reference_style_random_halos(built_library):
             nzero_filtered += 1
     assert nzero_filtered > 0
     engine.close()
+
+
+@pytest.mark.parametrize("concentration", [5.0, 10.0])
+def test_nfw_concentration_known_answer_through_the_engine(built_library, concentration):
+    """The reference's only physics known-answer test (tests/test_SO_properties.py:379-446): NFW halos of
+    10^4 particles, SO/200_crit/Concentration within 10 % of the input -- here six halos in one chunk through the
+    HIP engine, and the same numbers as the oracle to 1e-6 (the reference rounds the concentration to float32)."""
+    import dataclasses
+
+    from tests.test_oracle_invariants import _rnfw
+    from soap_amd.units import SnapshotScalars
+
+    sc = dataclasses.replace(SnapshotScalars(), boxsize=100.0)
+    npart, m_200 = 10000, 1.0e4
+    rho200 = 200.0 * sc.critical_density
+    r_200 = (m_200 / (rho200 * (4 / 3) * np.pi)) ** (1 / 3) / sc.a
+    pos, vel, grnr, cofp = [], [], [], []
+    for seed in range(6):
+        rng = np.random.RandomState(seed)
+        radius = np.sort(r_200 * _rnfw(rng, npart, concentration))
+        if radius[-1] < r_200:
+            radius[-1] = r_200 * 1.01
+        radius[0] = 0.0
+        phi = 2.0 * np.pi * rng.random_sample(npart)
+        st = 2.0 * rng.random_sample(npart) - 1.0
+        ct = np.sqrt((1.0 - st) * (1.0 + st))
+        centre = np.array([10.0 + 15.0 * seed, 50.0, 50.0]) + rng.random_sample(3)
+        pos.append(centre + np.stack([radius * np.cos(phi) * st, radius * np.sin(phi) * st, radius * ct], axis=1))
+        vel.append(1000.0 * (rng.random_sample((npart, 3)) - 0.5))
+        grnr.append(np.full(npart, 10 + seed, dtype=np.int32))
+        cofp.append(centre)
+    n = 6 * npart
+    data_np = {1: {"Coordinates": np.concatenate(pos) % sc.boxsize, "Velocities": np.concatenate(vel),
+                   "Masses": np.full(n, m_200 / npart), "GroupNr_bound": np.concatenate(grnr),
+                   "FOFGroupIDs": np.ones(n, dtype=np.int64)}}  # fmt: skip
+    halos_np = {"index": (np.arange(6) + 10).astype(np.int64), "cofp": np.array(cofp), "search_radius": np.full(6, 0.5 * r_200),
+                "read_radius": np.full(6, 6.0), "is_central": np.ones(6, dtype=np.int32),
+                "nr_bound_part": np.full(6, npart, dtype=np.int64)}  # fmt: skip
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}}
+    props = chp.build_halo_prop_list(sc, cf, so_vars, {})
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, {})
+    assert np.all(ha["done"] == 1) and np.all(ha_ref["done"] == 1)
+    got = np.array([helpers.engine_value(r, "SO/200_crit", "concentration_soft")[0] for r in results])
+    want = np.array([ref[i]["SO/200_crit/concentration_soft"].raw[0] for i in range(6)])
+    assert np.allclose(got, want, rtol=1e-6)
+    assert abs(np.median(got) / concentration - 1.0) < 0.1
+    engine.close()
