@@ -639,3 +639,77 @@ def test_nfw_concentration_known_answer_through_the_engine(built_library, concen
     assert np.allclose(got, want, rtol=1e-6)
     assert abs(np.median(got) / concentration - 1.0) < 0.1
     engine.close()
+
+
+def test_full_size_invariants_c3(built_library):
+    """BASELINE.json's metric configuration (C3: 1e8 particles, 1e5 halos, 16 calculations) is too large for
+    the oracle; at that size the engine is held to size-independent properties: bound-particle counts add up
+    to the catalogue's, every SO obeys M = 4/3 pi R^3 rho_ref, radii and masses are ordered the way their
+    thresholds are, nested spheres have nested counts, a second run reproduces the table bit for bit."""
+    import torch
+
+    import bench
+
+    import time as _t
+    _t0 = _t.time()
+    def _lap(msg):
+        print(f"[full-size] {msg}: {_t.time() - _t0:.1f} s", flush=True)
+    wl = bench.WORKLOADS["c3"]
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0")
+    cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
+    hn = {k: v.cpu().numpy() for k, v in halos.items()}
+    H = len(hn["index"])
+    _lap("chunk generated")
+    engine = halo_tasks.make_engine(sc, device=0)
+    tables = []
+    for rep in range(2):
+        halo_tasks.stage_chunk(engine, data)
+        ha = dict({k: v.copy() for k, v in hn.items()}, done=np.zeros(H, dtype=np.int32))
+        out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
+        tables.append(engine.fetch(table=True))
+        _lap(f"run {rep} fetched")
+    t, st = tables[0]["table"], tables[0]["status"]
+    assert np.array_equal(st, tables[1]["status"]) and np.array_equal(t, tables[1]["table"])
+    _lap("runs compared")
+    ok = st == 0
+    assert ok.sum() > 0.99 * H and np.all(st >= 0)
+    coloff = np.concatenate([[0], np.cumsum([layout.NCOLS[hp.kind] for hp in props])])
+    blk = {hp.name: t[ok][:, coloff[i] : coloff[i + 1]] for i, hp in enumerate(props)}
+    sub = blk["bound_subhalo"]
+    S, SO, AP = layout.SUBHALO_COLS, layout.SO_COLS, layout.APERTURE_COLS
+    # counts: exact
+    assert np.array_equal(sub[:, S["Ndm"][0]].astype(np.int64), hn["nr_bound_part"][ok])
+    assert np.all(sub[:, S["Ngas"][0]] == 0) and np.all(sub[:, S["Nstar"][0]] == 0)
+    central = hn["is_central"][ok] == 1
+    # every SO: M = 4/3 pi R^3 rho (SO_properties.py:209-214) wherever it exists; satellites have none
+    by_name = {hp.name: hp for hp in props}
+    radii = {}
+    for name, hp in by_name.items():
+        if hp.kind != layout.CALC_SO_DENSITY:
+            continue
+        b = blk[name]
+        R, M = b[:, SO["r"][0]], b[:, SO["Mtot"][0]]
+        assert np.all(R[~central] == 0)
+        ex = R > 0
+        rho = hp.calc_desc(props, props.index(hp)).reference_density
+        assert np.allclose(M[ex], 4.0 / 3.0 * np.pi * R[ex] ** 3 * rho, rtol=1e-12)
+        radii[rho] = R
+    rhos = sorted(radii)
+    for lo, hi in zip(rhos[:-1], rhos[1:]):
+        both = (radii[lo] > 0) & (radii[hi] > 0)
+        assert np.all(radii[lo][both] >= radii[hi][both])   # lower threshold, larger sphere
+    # nested inclusive spheres: counts and masses grow with the radius; exclusive <= inclusive
+    incl = sorted((hp.calc_desc(props, props.index(hp)).radius, hp.name) for hp in props if hp.kind == layout.CALC_APERTURE_INCL)
+    excl = sorted((hp.calc_desc(props, props.index(hp)).radius, hp.name) for hp in props if hp.kind == layout.CALC_APERTURE_EXCL)
+    for (r1, n1), (r2, n2) in zip(incl[:-1], incl[1:]):
+        assert np.all(blk[n1][:, AP["Ndm"][0]] <= blk[n2][:, AP["Ndm"][0]])
+        assert np.all(blk[n1][:, AP["Mtot"][0]] <= blk[n2][:, AP["Mtot"][0]] * (1 + 1e-12))
+    for (ri, ni), (re_, ne) in zip(incl, excl):
+        assert ri == re_
+        e, i_ = blk[ne][:, AP["Ndm"][0]], blk[ni][:, AP["Ndm"][0]]
+        assert np.all(e <= i_)
+        assert np.all(e <= sub[:, S["Ndm"][0]])
+    _lap("checks done")
+    engine.close()
+    del data
+    torch.cuda.empty_cache()
