@@ -713,3 +713,55 @@ def test_full_size_invariants_c3(built_library):
     engine.close()
     del data
     torch.cuda.empty_cache()
+
+
+def test_full_size_invariants_c5_hydro(built_library):
+    """The hydro configuration of BASELINE.json (C5, one GPU's share: 2.5e7 particles of four types, 2.5e4 halos,
+    24 calculations incl. projected apertures) at full size: the per-type bound counts add up to the catalogue's
+    numbers, the per-type masses add up to the totals, a projected aperture never holds more than the bound
+    subhalo, a second run reproduces the table bit for bit."""
+    import torch
+
+    import bench
+
+    wl = bench.WORKLOADS["c5"]
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0", hydro=True)
+    cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
+    hn = {k: v.cpu().numpy() for k, v in halos.items()}
+    H = len(hn["index"])
+    engine = halo_tasks.make_engine(sc, device=0)
+    tables = []
+    for rep in range(2):
+        halo_tasks.stage_chunk(engine, data)
+        ha = dict({k: v.copy() for k, v in hn.items()}, done=np.zeros(H, dtype=np.int32))
+        halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
+        tables.append(engine.fetch(table=True))
+    t, st = tables[0]["table"], tables[0]["status"]
+    assert np.array_equal(st, tables[1]["status"]) and np.array_equal(t, tables[1]["table"])
+    ok = st == 0
+    assert ok.sum() > 0.99 * H and np.all(st >= 0)
+    coloff = np.concatenate([[0], np.cumsum([layout.NCOLS[hp.kind] for hp in props])])
+    S, AP, PJ = layout.SUBHALO_COLS, layout.APERTURE_COLS, layout.PROJECTED_COLS
+    sub = t[ok][:, coloff[0] : coloff[1]]
+    ntot = sum(sub[:, S[k][0]] for k in ("Ngas", "Ndm", "Nstar", "Nbh"))
+    assert np.array_equal(ntot.astype(np.int64), hn["nr_bound_part"][ok])
+    assert sub[:, S["Ngas"][0]].sum() > 0 and sub[:, S["Nstar"][0]].sum() > 0
+    msum = sum(sub[:, S[k][0]] for k in ("Mgas", "Mdm", "Mstar", "Mbh_dynamical"))
+    assert np.allclose(msum, sub[:, S["Mtot"][0]], rtol=1e-12)
+    # half-mass radii lie inside the bound subhalo; baryons between nothing and everything
+    enc = sub[:, S["EncloseRadius"][0]]
+    for k in ("HalfMassRadiusTot", "HalfMassRadiusDM", "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"):
+        assert np.all(sub[:, S[k][0]] <= enc * (1 + 1e-12)), k
+    for i, hp in enumerate(props):
+        b = t[ok][:, coloff[i] : coloff[i + 1]]
+        if hp.kind in (layout.CALC_APERTURE_INCL, layout.CALC_APERTURE_EXCL):
+            m4 = sum(b[:, AP[k][0]] for k in ("Mgas", "Mdm", "Mstar", "Mbh_dynamical"))
+            assert np.allclose(m4, b[:, AP["Mtot"][0]], rtol=1e-12)
+        if hp.kind == layout.CALC_PROJECTED:
+            for p in range(3):
+                o = p * layout.PROJECTED_NCOLS
+                n4 = sum(b[:, o + PJ[k][0]] for k in ("Ngas", "Ndm", "Nstar", "Nbh"))
+                assert np.all(n4 <= ntot)
+    engine.close()
+    del data
+    torch.cuda.empty_cache()
