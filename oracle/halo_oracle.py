@@ -479,6 +479,11 @@ SCHEMA = {
     "HalfMassRadiusGas": (1, np.float32),
     "HalfMassRadiusStar": (1, np.float32),
     "HalfMassRadiusBaryon": (1, np.float32),
+    # neutrino particles inside an SO (property_table.py: NumberOfNeutrinoParticles, RawNeutrinoMass,
+    # NoiseSuppressedNeutrinoMass)
+    "Nnu": (1, np.uint32),
+    "Mnu": (1, np.float32),
+    "MnuNS": (1, np.float32),
 }
 
 
@@ -647,6 +652,7 @@ class SOProperties:
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
+        "Nnu", "Mnu", "MnuNS",
     ]  # fmt: skip
 
     def __init__(self, units: Units, SOval: float, type: str = "mean",
@@ -739,16 +745,28 @@ class SOProperties:
         fofid = np.concatenate(fofid)
         softening = np.concatenate(softening)
 
-        # compute_SO_radius_and_mass (SO_properties.py:356-513), no nu particles
+        # compute_SO_radius_and_mass (SO_properties.py:356-513)
         reference_density = self.reference_density
         physical_radius = self.physical_radius_comoving()
         if len(radius) == 0:
             return {}  # reference would fail on order[0]; nothing in the sphere -> zeros
-        order = np.argsort(radius)
-        ordered_radius = radius[order]
-        cumulative_mass = np.cumsum(mass[order], dtype=np.float64).astype(mass.dtype)
+        # neutrino particles (PartType6: weighted masses, may be negative) take part in the mass profile
+        # and in nothing else (SO_properties.py:380-395)
+        has_nu = 6 in data
+        if has_nu:
+            nu_mass = data[6]["Masses"] * data[6]["Weights"]
+            nu_pos = data[6]["Coordinates"] - centre[None, :]
+            nu_radius = np.sqrt(np.sum(nu_pos**2, axis=1))
+            all_mass = np.concatenate([mass, nu_mass])
+            all_r = np.concatenate([radius, nu_radius])
+        else:
+            all_mass, all_r = mass, radius
+        order = np.argsort(all_r)
+        ordered_radius = all_r[order]
+        cumulative_mass = np.cumsum(all_mass[order], dtype=np.float64).astype(mass.dtype)
         cumulative_mass += u.nu_density_comoving * 4.0 / 3.0 * np.pi * ordered_radius**3
-        fof0 = fofid[order[0]]
+        # FOF id of the innermost non-neutrino particle (SO_properties.py:407-409)
+        fof0 = fofid[order[order < radius.shape[0]][0]]
         nskip = max(1, int(np.argmax(ordered_radius > 0.0)))
         ordered_radius = ordered_radius[nskip:]
         cumulative_mass = cumulative_mass[nskip:]
@@ -805,6 +823,17 @@ class SOProperties:
 
         out = {"r": SO_r, "Mtot": SO_mass}
         out["Ngas"], out["Ndm"], out["Nstar"], out["Nbh"] = N[0], N[1], N[4], N[5]
+        nu_sum_m = nu_sum_mr = 0.0
+        out["Nnu"] = 0
+        if has_nu:
+            # SO_properties.py:507-511, :2689-2722
+            nu_sel = nu_radius < SO_r
+            out["Nnu"] = int(nu_sel.sum())
+            if out["Nnu"] != 0:
+                out["Mnu"] = data[6]["Masses"][nu_sel].sum()
+                out["MnuNS"] = (data[6]["Masses"][nu_sel] * data[6]["Weights"][nu_sel]).sum() + u.nu_density_comoving * SO_volume
+                nu_sum_m = np.sum(nu_mass[nu_sel])
+                nu_sum_mr = np.sum(nu_mass[nu_sel] * nu_radius[nu_sel])
         Mtotpart = mass.sum()
         frac = mass / Mtotpart if Mtotpart != 0 else None
         with np.errstate(all="ignore"):
@@ -836,9 +865,12 @@ class SOProperties:
                             ("concentration_soft", np.maximum(softening, radius))):  # fmt: skip
                 if rr.shape[0] < 10:
                     continue
-                # calculate_concentration (SO_properties.py:2738-2753), no nu particles
+                # calculate_concentration (SO_properties.py:2738-2753)
                 R1 = np.sum(mass * rr)
                 missed_mass = SO_mass - np.sum(mass)
+                if has_nu and out["Nnu"] != 0:
+                    R1 += nu_sum_mr
+                    missed_mass -= nu_sum_m
                 R1 += np.pi * u.nu_density_comoving * _qpow(SO_r, 4)
                 missed_mass -= u.nu_density_comoving * 4.0 / 3.0 * np.pi * _qpow(SO_r, 3)
                 R1 += missed_mass * SO_r

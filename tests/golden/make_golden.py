@@ -208,23 +208,37 @@ def main():
     rng = np.random.default_rng(4251)
     boxsize = 100.0
     soft = {f"PartType{t}": 0.0114 for t in (0, 1, 4, 5, 6)}
-    cosmology = {"nu_density": 0.0}
+    rng_nu = np.random.default_rng(66)   # separate stream: the cases without neutrinos keep their numbers
     cases = []
     for ic in range(40):
         n = int(rng.choice([1, 3, 12, 100, 600, 2500]))
         hydro = ic % 2 == 1
         types = (0, 1, 4, 5) if hydro else (1,)
         centre, data = random_halo(rng, n, boxsize, types)
+        # every other pair of cases also carries neutrino particles (PartType6: weighted masses, some negative)
+        # and a mean neutrino density (SO_properties.py:380-406)
+        nu_density = 0.0
+        if ic % 4 >= 2:
+            n_nu = int(rng_nu.integers(1, 300))
+            r_nu = rng_nu.exponential(1.0 / 25.0, n_nu)
+            ph, c2 = 2 * np.pi * rng_nu.random(n_nu), 2 * rng_nu.random(n_nu) - 1
+            s2 = np.sqrt((1 - c2) * (1 + c2))
+            data["PartType6"] = {
+                "Coordinates": centre + np.stack([r_nu * s2 * np.cos(ph), r_nu * s2 * np.sin(ph), r_nu * c2], axis=1),
+                "Masses": rng_nu.uniform(0.01, 0.05, n_nu), "Weights": rng_nu.normal(0.0, 0.5, n_nu),
+            }  # fmt: skip
+            nu_density = 0.4
+        cosmology = {"nu_density": U(nu_density)}
         udata = {pt: {k: U(v) for k, v in d.items()} for pt, d in data.items()}
         input_halo = {"cofp": U(centre), "index": 1, "is_central": 1}
         types_present = [f"PartType{t}" for t in (0, 1, 4, 5) if f"PartType{t}" in data]
-        case = dict(centre=centre, types=np.array(types), n=n)
+        case = dict(centre=centre, types=np.array(types), n=n, nu_density=np.array(nu_density))
         for pt, d in data.items():
             for k, v in d.items():
                 case[f"{pt}/{k}"] = v
         # SO: density type and fixed physical radius
-        allr = np.concatenate([np.sqrt(((d["Coordinates"] - centre) ** 2).sum(axis=1)) for d in data.values()])
-        mtot = sum(d.get("Masses", d.get("DynamicalMasses")).sum() for d in data.values())
+        allr = np.concatenate([np.sqrt(((d["Coordinates"] - centre) ** 2).sum(axis=1)) for pt, d in data.items() if pt != "PartType6"])
+        mtot = sum(d.get("Masses", d.get("DynamicalMasses")).sum() for pt, d in data.items() if pt != "PartType6")
         rmax = allr.max() if n > 1 else 1.0
         rho_ref = 30.0 * mtot / (4.0 / 3.0 * np.pi * max(rmax, 1e-3) ** 3)
         for tag, rho, rphys, virial in (("SOd", rho_ref, 0.0, True), ("SOp", 0.0, 0.6 * rmax, False)):
@@ -246,7 +260,8 @@ def main():
             for name in ["r", "Mtot", "Mtotpart", "com", "vcom", "Vmax_soft", "R_vmax_soft", "spin_parameter",
                          "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar", "Nbh",
                          "Mgas", "Mstar", "Mbh_dynamical", "concentration_unsoft", "concentration_soft",
-                         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"]:
+                         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
+                         "Nnu", "Mnu", "MnuNS"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # apertures

@@ -10,6 +10,7 @@ ISA; on the host that generated the vectors everything matches bit-for-bit, else
 pow-dependent values may move by an ulp, hence RTOL below instead of `==` for those.
 """
 
+import dataclasses
 import os
 
 import numpy as np
@@ -91,6 +92,8 @@ def _case(g, i):
             d[f] = c[f"PartType{t}/{f}"]
         d["Masses"] = c[f"PartType{t}/DynamicalMasses"] if t == 5 else c[f"PartType{t}/Masses"]
         data[int(t)] = d
+    if "PartType6/Masses" in c:   # neutrino particles: coordinates, masses, weights only
+        data[6] = {f: c[f"PartType6/{f}"] for f in ("Coordinates", "Masses", "Weights")}
     return c, data
 
 
@@ -114,12 +117,13 @@ def test_particle_data_classes_match_reference():
     """SOParticleData / ApertureParticleData / SubhaloParticleData / projected classes of the
     reference, property by property, on random single- and multi-type halos."""
     g = np.load(os.path.join(GOLD, "particle_data_classes.npz"))
-    u = _units(g)
-    n_so = n_ap = 0
+    u0 = _units(g)
+    n_so = n_ap = n_nu = 0
     for i in range(int(g["ncases"])):
         c, data = _case(g, i)
+        u = dataclasses.replace(u0, nu_density=float(c["nu_density"]))
         input_halo = {"cofp": c["centre"], "index": 1, "is_central": 1}
-        nb = sum(int((d["GroupNr_bound"] == 1).sum()) for d in data.values())
+        nb = sum(int((d["GroupNr_bound"] == 1).sum()) for t, d in data.items() if t != 6)
         input_halo["nr_bound_part"] = nb
         # --- SO, density threshold and fixed radius
         for tag in ("SOd", "SOp"):
@@ -146,6 +150,8 @@ def test_particle_data_classes_match_reference():
                                  "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar",
                                  "Nbh", "Mgas", "Mstar", "Mbh_dynamical"])  # fmt: skip
             _check(tag, out, c, ["com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"])
+            _check(tag, out, c, ["Nnu", "Mnu", "MnuNS"])
+            n_nu += int(6 in data and out.get("Nnu", 0) > 0)
             # concentration: the reference rounds to float32 (SO_properties.py:2735)
             _check(tag, out, c, ["concentration_unsoft", "concentration_soft"], exact=False)
         # --- apertures
@@ -193,4 +199,4 @@ def test_particle_data_classes_match_reference():
                                                 "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
                                                 "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
                                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
-    assert n_so > 20 and n_ap > 40
+    assert n_so > 20 and n_ap > 40 and n_nu > 8
