@@ -135,6 +135,16 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n
                                     int32_t resolution, int32_t on_device);
 
 /*
+ * Stage the chunk's neutrino particles (PartType6) and build their mesh.  They enter the spherical-overdensity
+ * mass profile with mass * weight (weights may be negative) and feed NumberOfNeutrinoParticles /
+ * RawNeutrinoMass / NoiseSuppressedNeutrinoMass and the neutrino terms of the concentration; nothing else
+ * sees them (SO_properties.py:380-395, :507-511, :2689-2753).  With on_device == 1 `mass` must stay valid
+ * until the next staging call; `weight` is consumed here.  n == 0 removes them.
+ */
+int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const double *mass,
+                                    const double *weight, int32_t resolution, int32_t on_device);
+
+/*
  * Stage the chunk's halo table (halo_arrays of process_halos, halo_tasks.py:276-287),
  * in processing order (the reference sorts by nr_bound_part descending,
  * chunk_tasks.py:118-120).  Host pointers.

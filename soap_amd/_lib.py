@@ -59,6 +59,10 @@ SYMBOLS = {
         C.c_int32,
         [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_int32, C.c_void_p, C.c_int32, C.c_int32],
+    ),
+    "soap_engine_stage_neutrinos": (
+        C.c_int32,
+        [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32],
     ),  # fmt: skip
     "soap_engine_stage_halos": (
         C.c_int32,

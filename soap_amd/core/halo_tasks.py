@@ -83,12 +83,21 @@ def stage_chunk(engine: Engine, data: Dict, resolution=None):
     the counterpart of share_array + SharedMesh(comm, pos, resolution) in
     ChunkTask.__call__ (SOAP/core/chunk_tasks.py:165-170, :293-304).
     data[ptype] = {"Coordinates","Velocities","Masses"|"DynamicalMasses","GroupNr_bound",
-    "FOFGroupIDs"}; ptype is 0/1/4/5 or "PartType0"...; arrays are NumPy or torch-CUDA.
+    "FOFGroupIDs"}; ptype is 0/1/4/5 or "PartType0"...; data[6] = {"Coordinates","Masses","Weights"};
+    arrays are NumPy or torch-CUDA.  Types absent from `data` are removed from the engine.
     """
+    present = {int(str(p)[-1]) if not isinstance(p, int) else p for p in data}
+    for pt in (0, 1, 4, 5, 6):
+        if pt not in present:   # a type the previous chunk had and this one has not
+            engine.clear_type("nu" if pt == 6 else SLOT_OF_PTYPE[pt])
     for ptype, d in data.items():
         pt = int(str(ptype)[-1]) if not isinstance(ptype, int) else ptype
+        if pt == 6:   # neutrinos: coordinates, masses, weights -- SO mass profile only
+            res = mesh_resolution(int(d["Coordinates"].shape[0])) if resolution is None else resolution
+            engine.stage_neutrinos(d["Coordinates"], d["Masses"], d["Weights"], res)
+            continue
         if pt not in SLOT_OF_PTYPE:
-            continue  # neutrinos (PartType6) are not part of the engine yet
+            continue
         n = int(d["Coordinates"].shape[0])
         mass = d["DynamicalMasses"] if (pt == 5 and "DynamicalMasses" in d) else d["Masses"]
         res = mesh_resolution(n) if resolution is None else resolution

@@ -43,15 +43,19 @@
 #define BLK 256
 #define NWAVE (BLK / 64)
 #define CH 4096            // LDS sort chunk (elements)
-#define PIDX_BITS 30
+#define PIDX_BITS 29   // packed slab index: 3 bits of type slot, 29 bits of cell-ordered position
 #define PIDX_MASK ((1u << PIDX_BITS) - 1u)
 #define MAXCALC 32
 
 // flags byte of a slab element
-#define FL_TYPE 0x3
-#define FL_BOUND 0x4
-#define FL_SAT 0x8
-#define FL_EXT 0x10
+#define FL_TYPE 0x7    // type slot 0..3, or NU_SLOT
+#define FL_BOUND 0x8
+#define FL_SAT 0x10
+#define FL_EXT 0x20
+// Neutrino particles (PartType6) are a fifth, internal type slot: they enter the SO mass profile with their
+// weighted mass and nothing else (SO_properties.py:380-395); no velocities, no group membership.
+#define NU_SLOT 4
+#define NT_ALL 5
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -70,7 +74,8 @@ struct TypeDev {
     int res;
     int grnr64;
     const double *x, *y, *z;      // coordinates in mesh-cell order (SoA): what the candidate stream reads
-    const double *vel, *mass;     // the caller's arrays (AoS velocities), indexed through `orig`
+    const double *vel, *mass;     // the caller's arrays (AoS velocities), indexed through `orig`; for NU_SLOT: vel = raw
+                                  // (unweighted) masses, mass = mass * weight
     const int *grnr32;
     const long long *grnr64p;
     const long long *fof;
@@ -100,7 +105,7 @@ struct HaloDev {
 };
 
 struct RunParams {
-    TypeDev t[SOAP_NTYPES];
+    TypeDev t[NT_ALL];
     SlabDev slab;
     HaloDev halo;
     double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
@@ -109,6 +114,7 @@ struct RunParams {
     int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
     int hydro;             // gas or star particles staged: the baryon kinematics are computed
     int dm_only;           // only dark matter staged
+    int has_nu;            // neutrino particles staged
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;
@@ -467,7 +473,7 @@ __global__ void k_reorder(const unsigned *sort_idx, long long n, const double *p
 // ------------------------------------------------------------------------------------------
 // per-halo kernel
 // ------------------------------------------------------------------------------------------
-#define NACC 72
+#define NACC 76
 #define PREFB 12        // calculations whose prefix moments are finalised together
 #define NHM 5           // half-mass weight classes: all, dark matter, gas, stars, baryons
 enum {
@@ -489,7 +495,9 @@ enum {
     // sum m*x (3), sum m*v' (3), sum m * x cross v' (3), sum m v'_a v'_b (6)
     A_GMX = 38, A_GMV = 41, A_GL = 44, A_GVV = 47,
     A_SMX = 53, A_SMV = 56, A_SL = 59, A_SVV = 62,
-    A_NSUM = 68                        // accumulators in use (the last slots of NACC are scratch)
+    // neutrino particles inside the selection: count, raw mass, weighted mass, weighted mass * radius
+    A_NUN = 68, A_NUM = 69, A_NUW = 70, A_NUR = 71,
+    A_NSUM = 72                        // accumulators in use (the last slots of NACC are scratch)
 };
 
 #define GAS __attribute__((address_space(1)))
@@ -604,7 +612,7 @@ __global__ void k_estimate(const RunParams *Pp, long long *est) {
     if (h >= P.halo.n) return;
     double R = fmin(P.halo.read_radius[h], P.halo.search_radius[h] * P.first_factor);
     long long tot = 0;
-    for (int ts = 0; ts < SOAP_NTYPES; ts++) {
+    for (int ts = 0; ts < NT_ALL; ts++) {
         const TypeDev &T = P.t[ts];
         if (T.n == 0) continue;
         Mask256 mk[3];
@@ -714,7 +722,7 @@ struct soap_engine {
     hipStream_t stream = nullptr;
     bool own_streams = false;   // one priority stream per class
     DevPool pool;
-    TypeHost t[SOAP_NTYPES];
+    TypeHost t[NT_ALL];
     // halos
     long long n_halo = 0;
     double *d_cofp = nullptr, *d_search = nullptr, *d_read = nullptr;
@@ -850,7 +858,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    for (int t = 0; t < SOAP_NTYPES; t++) h->t[t].release(h->pool);
+    for (int t = 0; t < NT_ALL; t++) h->t[t].release(h->pool);
     h->pool.purge();
     free_halos(h);
     free_slabs(h);
@@ -874,13 +882,39 @@ int32_t soap_engine_destroy(soap_engine *h) {
     return 0;
 }
 
+// weighted neutrino masses  m_eff = mass * weight  (SO_properties.py:381-383)
+__global__ void k_weighted_mass(const double *mass, const double *weight, long long n, double *out) {
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK)
+        out[i] = mass[i] * weight[i];
+}
+
+static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const double *vel,
+                          const double *mass, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
+                          int32_t resolution, int32_t on_device);
+
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const double *pos,
                                     const double *vel, const double *mass, const void *grnr,
                                     int32_t grnr_bytes, const int64_t *fof, int32_t resolution,
                                     int32_t on_device) {
     if (!h) return fail(-1, "null handle");
     if (ts < 0 || ts >= SOAP_NTYPES) return fail(-2, "type_slot out of range");
-    if (n < 0 || n >= (1ll << PIDX_BITS)) return fail(-3, "particle count per type must be < 2^30");
+    if (n > 0 && (!vel || !grnr || !fof)) return fail(-6, "null particle array");
+    return stage_type(h, ts, n, pos, vel, mass, grnr, grnr_bytes, fof, resolution, on_device);
+}
+
+int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const double *mass,
+                                    const double *weight, int32_t resolution, int32_t on_device) {
+    if (!h) return fail(-1, "null handle");
+    if (n > 0 && !weight) return fail(-6, "null particle array");
+    // the weights ride in the `vel` argument (3 doubles per particle are not needed: one is), ids are absent
+    return stage_type(h, NU_SLOT, n, pos, weight, mass, nullptr, 4, nullptr, resolution, on_device);
+}
+
+static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const double *vel,
+                          const double *mass, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
+                          int32_t resolution, int32_t on_device) {
+    const bool nu = ts == NU_SLOT;
+    if (n < 0 || n >= (1ll << PIDX_BITS)) return fail(-3, "particle count per type must be < 2^29");
     if (grnr_bytes != 4 && grnr_bytes != 8) return fail(-4, "grnr_bytes must be 4 or 8");
     if (resolution < 1 || resolution > 256) return fail(-5, "mesh resolution must be in [1,256]");
     HIPCHECK(hipSetDevice(h->cfg.device));
@@ -888,24 +922,27 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     DevPool &pool = h->pool;
     T.release(pool);
     if (n == 0) return 0;   // SharedMesh.empty (shared_mesh.py:25-27)
-    if (!pos || !vel || !mass || !grnr || !fof) return fail(-6, "null particle array");
+    if (!pos || !vel || !mass) return fail(-6, "null particle array");
     hipStream_t st = h->stream;
     const double *dpos = pos, *dvel = vel, *dmass = mass;
     const void *dgr = grnr;
     const long long *dfof = (const long long *)fof;
     std::vector<std::pair<void *, size_t>> tmp;
     if (!on_device) {
-        void *a, *b, *c, *d, *e;
+        const size_t vbytes = (size_t)n * (nu ? 8 : 24);   // neutrinos: one weight per particle in place of a velocity
+        void *a, *b, *c, *d = nullptr, *e = nullptr;
         HIPCHECK(pool.alloc(&a, (size_t)n * 24)); tmp.push_back({a, (size_t)n * 24});
-        HIPCHECK(pool.alloc(&b, (size_t)n * 24)); tmp.push_back({b, (size_t)n * 24});
+        HIPCHECK(pool.alloc(&b, vbytes)); tmp.push_back({b, vbytes});
         HIPCHECK(pool.alloc(&c, (size_t)n * 8)); tmp.push_back({c, (size_t)n * 8});
-        HIPCHECK(pool.alloc(&d, (size_t)n * grnr_bytes)); tmp.push_back({d, (size_t)n * grnr_bytes});
-        HIPCHECK(pool.alloc(&e, (size_t)n * 8)); tmp.push_back({e, (size_t)n * 8});
         HIPCHECK(hipMemcpyAsync(a, pos, (size_t)n * 24, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(b, vel, (size_t)n * 24, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(b, vel, vbytes, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d, grnr, (size_t)n * grnr_bytes, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(e, fof, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        if (!nu) {
+            HIPCHECK(pool.alloc(&d, (size_t)n * grnr_bytes)); tmp.push_back({d, (size_t)n * grnr_bytes});
+            HIPCHECK(pool.alloc(&e, (size_t)n * 8)); tmp.push_back({e, (size_t)n * 8});
+            HIPCHECK(hipMemcpyAsync(d, grnr, (size_t)n * grnr_bytes, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(e, fof, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        }
         dpos = (const double *)a; dvel = (const double *)b; dmass = (const double *)c;
         dgr = d; dfof = (const long long *)e;
     }
@@ -969,6 +1006,16 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const
     for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
     T.vel = dvel; T.mass = dmass; T.fof = dfof;
     if (T.grnr64) T.g64 = (const long long *)dgr; else T.g32 = (const int *)dgr;
+    if (nu) {
+        // profile mass = mass * weight (owned array); the raw masses take the place of the velocities
+        double *meff;
+        HIPCHECK(pool.alloc((void **)&meff, (size_t)n * 8));
+        hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (long long)n, meff);
+        T.owned.push_back({meff, (size_t)n * 8});
+        T.vel = dmass;
+        T.mass = meff;
+        T.g32 = nullptr; T.g64 = nullptr; T.fof = nullptr;
+    }
     hipEvent_t ev2;
     HIPCHECK(hipEventCreate(&ev2));
     hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLK), 0, st, d_sortidx, (long long)n, dpos, T.x, T.y, T.z);
@@ -1075,20 +1122,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipMemcpyAsync(h->d_coloff, coloff.data(), (size_t)n_calcs * 4, hipMemcpyHostToDevice, st));
 
     long long ntot = 0;
-    for (int t = 0; t < SOAP_NTYPES; t++) ntot += h->t[t].n;
+    for (int t = 0; t < NT_ALL; t++) ntot += h->t[t].n;
     // room for every staged particle plus the power-of-two padding of the fallback sort of an appended shell
     const long long cap_max = 2 * next_pow2(std::max<long long>(ntot, 64));
 
     RunParams P;
     memset(&P, 0, sizeof(P));
-    for (int t = 0; t < SOAP_NTYPES; t++) {
+    for (int t = 0; t < NT_ALL; t++) {
         const TypeHost &T = h->t[t];
         TypeDev &D = P.t[t];
         D.n = T.n; D.res = T.res; D.grnr64 = T.grnr64;
         D.x = T.x; D.y = T.y; D.z = T.z; D.vel = T.vel; D.mass = T.mass;
         D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset;
         for (int d = 0; d < 3; d++) { D.pos_min[d] = T.pos_min[d]; D.pos_max[d] = T.pos_max[d]; D.cell_size[d] = T.cell_size[d]; }
-        P.soft[t] = h->cfg.softening[t];
+        if (t < SOAP_NTYPES) P.soft[t] = h->cfg.softening[t];
     }
     P.halo.n = h->n_halo; P.halo.cofp = h->d_cofp; P.halo.search_radius = h->d_search; P.halo.read_radius = h->d_read;
     P.halo.index = h->d_index; P.halo.is_central = h->d_central; P.halo.nr_bound = h->d_nrbound;
@@ -1105,7 +1152,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     }
     { const char *e = getenv("SOAP_ENGINE_PROFILE"); P.profile = e ? atoi(e) : 0; }
     P.hydro = (h->t[0].n > 0 || h->t[2].n > 0) ? 1 : 0;
-    P.dm_only = (h->t[0].n == 0 && h->t[2].n == 0 && h->t[3].n == 0) ? 1 : 0;
+    P.has_nu = h->t[NU_SLOT].n > 0 ? 1 : 0;
+    P.dm_only = (h->t[0].n == 0 && h->t[2].n == 0 && h->t[3].n == 0 && !P.has_nu) ? 1 : 0;
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;

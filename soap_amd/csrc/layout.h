@@ -30,7 +30,8 @@ enum {
     SOC_spin = 23, SOC_conc_unsoft, SOC_conc_soft,
     SOC_com_gas = 26, SOC_com_star = 29, SOC_vcom_gas = 32, SOC_vcom_star = 35,
     SOC_Lgas = 38, SOC_Lstar = 41, SOC_Lbaryons = 44,
-    SOC_NCOLS = 47
+    SOC_Nnu = 47, SOC_Mnu, SOC_MnuNS,   // neutrino particles inside the sphere
+    SOC_NCOLS = 50
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {

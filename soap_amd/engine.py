@@ -138,6 +138,29 @@ class Engine:
         # (include/soap_engine.h, lifetime rule): hold on to them (they may be widened / contiguous copies)
         self._staged[int(type_slot)] = (k2, k3, k4, k5) if dev else None
 
+    def clear_type(self, type_slot):
+        """Mark a particle type as absent from the current chunk (type_slot 0..3, or "nu")."""
+        if type_slot == "nu":
+            self._check(self._lib.soap_engine_stage_neutrinos(self._h, 0, None, None, None, 1, 0))
+        else:
+            self._check(self._lib.soap_engine_stage_particles(self._h, int(type_slot), 0, None, None, None, None, 4, None, 1, 0))
+        self._staged[type_slot] = None
+
+    def stage_neutrinos(self, pos, mass, weight, resolution=None):
+        """PartType6: Coordinates, Masses, Weights (SO mass profile only, SO_properties.py:380-395)."""
+        n = int(pos.shape[0])
+        if resolution is None:
+            resolution = mesh_resolution(n)
+        p_pos, dev, k1 = _ptr(pos, np.float64)
+        p_m, dev2, k2 = _ptr(mass, np.float64)
+        p_w, dev3, k3 = _ptr(weight, np.float64)
+        if len({dev, dev2, dev3}) != 1:
+            raise ValueError("all particle arrays must live on the same side (host or device)")
+        if n and tuple(pos.shape) != (n, 3):
+            raise ValueError("Coordinates must have shape (n, 3)")
+        self._check(self._lib.soap_engine_stage_neutrinos(self._h, n, p_pos, p_m, p_w, int(resolution), 1 if dev else 0))
+        self._staged["nu"] = (k2,) if dev else None
+
     def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part):
         n = int(np.asarray(index).shape[0])
         a = [

@@ -33,6 +33,7 @@ SO_COLS = {
     "concentration_unsoft": (24, 1), "concentration_soft": (25, 1),
     "com_gas": (26, 3), "com_star": (29, 3), "vcom_gas": (32, 3), "vcom_star": (35, 3),
     "Lgas": (38, 3), "Lstar": (41, 3), "Lbaryons": (44, 3),
+    "Nnu": (47, 1), "Mnu": (48, 1), "MnuNS": (49, 1),
 }  # fmt: skip
 APERTURE_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -54,9 +55,9 @@ PROJECTED_NCOLS = 25
 
 NCOLS = {
     CALC_SUBHALO: 58,
-    CALC_SO_DENSITY: 47,
-    CALC_SO_PHYSICAL: 47,
-    CALC_SO_MULTIPLE: 47,
+    CALC_SO_DENSITY: 50,
+    CALC_SO_PHYSICAL: 50,
+    CALC_SO_MULTIPLE: 50,
     CALC_APERTURE_INCL: 57,
     CALC_APERTURE_EXCL: 57,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,

@@ -79,6 +79,9 @@ full_property_list = {
     "proj_veldisp_star": Property("StellarProjectedVelocityDispersion", 1, np.float32, _V, True, 0, False, 0, "Stellar velocity dispersion along the projection axis."),
     "HalfMassRadiusGas": Property("HalfMassRadiusGas", 1, np.float32, _Lc, False, 1, False, 0, "Gas half mass radius."),
     "HalfMassRadiusStar": Property("HalfMassRadiusStars", 1, np.float32, _Lc, False, 1, False, 0, "Stellar half mass radius."),
+    "Nnu": Property("NumberOfNeutrinoParticles", 1, np.uint32, "dimensionless", True, None, True, 0, "Number of neutrino particles."),
+    "Mnu": Property("RawNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Total mass of the neutrino particles, without their weights."),
+    "MnuNS": Property("NoiseSuppressedNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Weighted neutrino particle mass plus the mean neutrino density times the SO volume."),
     "HalfMassRadiusBaryon": Property("HalfMassRadiusBaryons", 1, np.float32, _Lc, False, 1, False, 0, "Baryonic (gas and stars) half mass radius."),
 }  # fmt: skip
 

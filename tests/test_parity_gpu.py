@@ -22,7 +22,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-COUNT_KEYS = ("Ndm", "Ngas", "Nstar", "Nbh")
+COUNT_KEYS = ("Ndm", "Ngas", "Nstar", "Nbh", "Nnu")
 
 
 def _scales(o, group):
@@ -765,3 +765,41 @@ def test_full_size_invariants_c5_hydro(built_library):
     engine.close()
     del data
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("engine_kw", [{}, {"slab_capacity": 256, "n_workgroups": 8}], ids=["default-classes", "small-slab"])
+def test_neutrino_particles_in_the_SO_profile(built_library, engine_kw):
+    """PartType6: weighted masses (some negative) take part in the SO mass profile, together with a mean
+    neutrino density, and feed NumberOfNeutrinoParticles / RawNeutrinoMass / NoiseSuppressedNeutrinoMass and
+    the concentration; apertures, the bound subhalo and the enclosed-density test of the radius loop ignore
+    them (SO_properties.py:380-395, :507-511, :2689-2753; halo_tasks.py:85-103)."""
+    import dataclasses
+
+    sc, data, halos = make_chunk(120000, 80, seed=61)
+    sc = dataclasses.replace(sc, nu_density=0.05 * sc.mean_density)
+    data_np, halos_np = to_numpy(data, halos)
+    rng = np.random.default_rng(5)
+    n_nu = 60000
+    pos_nu = rng.uniform(0.0, sc.boxsize, (n_nu, 3))
+    # half of the neutrino particles follow the halos
+    hsel = rng.integers(0, len(halos_np["index"]), n_nu // 2)
+    pos_nu[: n_nu // 2] = (halos_np["cofp"][hsel] + rng.normal(0.0, 0.3, (n_nu // 2, 3))) % sc.boxsize
+    mean_m = float(np.mean(data_np[1]["Masses"]))
+    data_np[6] = {"Coordinates": pos_nu, "Masses": rng.uniform(0.05, 0.15, n_nu) * mean_m,
+                  "Weights": rng.normal(0.2, 0.6, n_nu)}  # fmt: skip
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "200_mean": {"value": 200.0, "type": "mean"},
+               "500_crit": {"value": 500.0, "type": "crit"}, "BN98": {"value": 0.0, "type": "BN98"},
+               "5xR_500_crit": {"value": 500.0, "type": "crit", "radius_multiple": 5.0}}  # fmt: skip
+    ap_vars = chp.aperture_variations((50.0, 100.0))
+    props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars)
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props, **engine_kw)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, ap_vars)
+    assert np.array_equal(ha["done"], ha_ref["done"]) and ha["done"].sum() > 40
+    assert np.array_equal(ha["read_radius"], ha_ref["read_radius"]) and np.array_equal(ha["search_radius"], ha_ref["search_radius"])
+    nnu = 0
+    for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+        compare_halo(ref[row], results[j], sc)
+        nnu += int(helpers.engine_value(results[j], "SO/200_mean", "Nnu")[0])
+    assert nnu > 100
+    engine.close()
