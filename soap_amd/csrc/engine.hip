@@ -10,17 +10,19 @@
 //   SOAP/property_calculation/{half_mass_radius,kinematic_properties}.py
 //
 // Design (DESIGN.md has the long form):
-//   * particles of each type are physically reordered into mesh-cell order (SoA in HBM) so the
-//     cells a search sphere overlaps are a few contiguous runs -> coalesced reads;
-//   * one 256-thread workgroup per halo, halos pulled from a device queue in the staged
-//     (largest-first) order by a persistent grid;
-//   * per halo: stream candidate runs, exact periodic distance test, compact the selected
-//     particles into the workgroup's slab, bitonic sort by radius (LDS for <=4096 particles,
-//     LDS+L2 above), ONE sequential fp64 cumulative-mass pass (bit-identical to
-//     numpy.cumsum, so SO radii and hence SO membership are reproducible), then every
-//     SO / aperture / subhalo calculation is a masked reduction + a masked scan over the
-//     sorted slab (wavefront shuffles, LDS across the 4 waves).
-//   * no MFMA anywhere: the path is bandwidth/latency bound fp64 vector work.
+//   * the COORDINATES of each type are physically reordered into mesh-cell order (SoA in HBM) so the cells a
+//     search sphere overlaps are a few contiguous runs -> coalesced reads; velocities, masses and ids stay in
+//     the caller's arrays and are gathered through the permutation for the particles a halo selects;
+//   * one thread group per halo -- a wavefront, 256 or 1024 threads, chosen from a cheap work estimate -- in
+//     three persistent kernels (halo_kernel.inc compiled three times) that run concurrently on priority
+//     streams and pull halos heaviest-first from device queues;
+//   * per halo: stream candidate runs, exact periodic distance test, compact the selected particles into
+//     the group's slab, sort by radius (LDS bitonic / sample sort), ONE sequential fp64 cumulative-mass chain
+//     (bit-identical to numpy.cumsum, so SO radii and hence SO membership are reproducible); the reference's
+//     x1.2 radius rounds are emulated on prefixes of that sorted slab; every SO / sphere / subhalo /
+//     projected-aperture calculation is then a prefix of it, evaluated in fused passes with
+//     lanes = calculations for everything that is per calculation;
+//   * no MFMA anywhere: the path is latency / issue bound fp64 vector work.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <functional>
