@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SOAP_ENGINE_ABI_VERSION 1
+#define SOAP_ENGINE_ABI_VERSION 2
 
 /* particle types the selections know about, in the reference's concatenation order
  * (SO_properties.py:3520-3550).  "slot" below is the position in this list. */
@@ -55,6 +55,12 @@ typedef struct soap_engine_config {
     double softening[SOAP_NTYPES]; /* comoving code length per type slot */
     int32_t n_workgroups;   /* 0 = library default (persistent grid size) */
     int32_t slab_capacity;  /* 0 = default; max particles in one halo's search sphere */
+    /* pseudo-evolution term of the flow rates through spherical shells
+     * (SO_properties.py:2875-2884, cosmology from :3446-3451):
+     *   R_dot = (2/3) (G M_SO H / 100)^(1/3) (2 Omega_g + 3/2 Omega_m) R_frac */
+    double G_phys;          /* Newton G in physical code units */
+    double hubble;          /* H(z) in 1 / code time */
+    double rdot_omega;      /* 2 Omega_g + 3/2 Omega_m */
 } soap_engine_config;
 
 /* calculation kinds: one per HaloProperty subclass on the path */
@@ -88,8 +94,15 @@ typedef struct soap_calc_desc {
     int32_t filter_limit;        /* category filter of the calculation: minimum number of
                                     bound particles (0 = "basic"), category_filter.py:69-106 */
     int32_t filter_types;        /* bit mask over type slots counted by the filter */
-    int32_t reserved;
+    int32_t flags;               /* SOAP_CALC_FLAG_* */
 } soap_calc_desc;
+
+/* soap_calc_desc.flags */
+enum {
+    SOAP_CALC_FLAG_DM_FLOW = 1     /* SO_DENSITY with a virial definition: DarkMatterMassFlowRate is wanted
+                                      (SO_properties.py:2919-2932); the outer shell reaches 1.05 R_SO, beyond
+                                      the search radius the calculation raises SearchRadiusTooSmallError */
+};
 
 /* per-halo status column */
 enum {

@@ -69,6 +69,11 @@ class Units:
     softening: Dict[int, float]  # per ptype, PHYSICAL code length
     nu_density: float = 0.0  # PHYSICAL code density of the nu background
     virBN98: float = 0.0
+    # flow rates through spherical shells (SO_properties.py:3446-3451): Hubble rate in 1 / code time,
+    # radiation and matter density parameters at this redshift
+    H: float = 0.0
+    Omega_g: float = 0.0
+    Omega_m: float = 0.0
 
     # --- the single explicit conversions (DESIGN.md "Units") ---
     def kpc_to_comoving(self, r_kpc: float) -> float:
@@ -123,6 +128,9 @@ def flamingo_like_units(boxsize: float = 100.0) -> Units:
         softening={0: soft, 1: soft, 4: soft, 5: soft},
         nu_density=0.0,
         virBN98=float(virBN98),
+        H=79.60499176,
+        Omega_g=5.33243487e-05,
+        Omega_m=Omega_m,
     )
 
 
@@ -484,6 +492,8 @@ SCHEMA = {
     "Nnu": (1, np.uint32),
     "Mnu": (1, np.float32),
     "MnuNS": (1, np.float32),
+    # inflow at 0.1 / 0.3 / 1 R_SO, outflow at 0.1 / 0.3 / 1 R_SO (property_table.py:3327-3342)
+    "DarkMatterMassFlowRate": (6, np.float32),
 }
 
 
@@ -652,7 +662,7 @@ class SOProperties:
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
-        "Nnu", "Mnu", "MnuNS",
+        "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate",
     ]  # fmt: skip
 
     def __init__(self, units: Units, SOval: float, type: str = "mean",
@@ -812,6 +822,8 @@ class SOProperties:
 
         sel = radius < SO_r
         N = {t: int((radius[types == t] < SO_r).sum()) for t in PTYPES}
+        all_dm = types == 1   # every dark matter particle of the search sphere (flow rate through the outer shell)
+        dm_all_mass, dm_all_pos, dm_all_vel = mass[all_dm], position[all_dm], velocity[all_dm]
         mass = mass[sel]
         radius = radius[sel]
         position = position[sel]
@@ -876,7 +888,50 @@ class SOProperties:
                 R1 += missed_mass * SO_r
                 R1 /= SO_r * SO_mass
                 out[key] = concentration_from_R1(R1)
+        if self.virial_definition and N[1] != 0:
+            # DarkMatterMassFlowRate (SO_properties.py:2919-2932): all loaded dark matter, not only r < R_SO
+            out["DarkMatterMassFlowRate"] = mass_flow_rate(
+                dm_all_pos, dm_all_mass, dm_all_vel, SO_r, SO_mass, search_radius,
+                mass, velocity, radius, vcom, u)
         return out
+
+
+def mass_flow_rate(positions, masses, velocities, SO_r, SO_mass, search_radius, so_mass, so_velocity, so_radius, vcom, u):
+    """
+    calculate_flow_rate(flow_type="mass", pseudo_evolve=True, hubble=False) (SO_properties.py:2816-2916):
+    mass flux through shells of width 0.1 R centred on R = 0.1, 0.3, 1 R_SO, relative to the centre-of-mass
+    velocity of ALL particles inside that radius (vcom_ten_percent / vcom_thirty_percent :2791-2814, vcom)
+    and to the pseudo-evolution of R_SO; inflow (v_r < 0) and outflow (v_r > 0) separately.  Raises
+    SearchRadiusTooSmallError when the outermost shell reaches beyond the search radius (:2849-2850).
+    Lengths are comoving here, so the rates carry 1/a relative to the table unit (applied at the cast).
+    """
+    radii = np.sqrt(np.sum(positions**2, axis=1))
+    R_fracs = [0.1, 0.3, 1]
+    rates = np.zeros(6)
+    for i_R, R_frac in enumerate(R_fracs):
+        R = R_frac * SO_r
+        dR = 0.1 * R
+        if search_radius is not None and R + (dR / 2) > search_radius:
+            raise SearchRadiusTooSmallError
+        r_mask = (R - (dR / 2) < radii) & (radii < R + (dR / 2))
+        if R_frac == 1:
+            vc = vcom
+        else:
+            mask = so_radius < R_frac * SO_r
+            if not np.sum(mask):
+                vc = np.zeros(3)   # "This shouldn't happen, but HaloCentre doesn't actually need to be on top of a particle"
+            else:
+                vc = (so_mass[mask, None] * so_velocity[mask]).sum(axis=0) / so_mass[mask].sum()
+        r_hat = positions[r_mask] / np.stack(3 * [radii[r_mask]], axis=1)
+        v_r = np.sum((velocities[r_mask] - vc[None, :]) * r_hat, axis=1)
+        R_dot = (2 / 3) * (u.G * SO_mass * u.H / 100) ** (1 / 3)
+        R_dot *= 2 * u.Omega_g + (3 / 2) * u.Omega_m
+        R_dot *= R_frac
+        v_r -= R_dot
+        flow_rate = masses[r_mask] * np.abs(v_r)
+        rates[i_R] = np.sum(flow_rate[v_r < 0]) / dR
+        rates[i_R + 3] = np.sum(flow_rate[v_r > 0]) / dR
+    return rates
 
 
 class RadiusMultipleSOProperties(SOProperties):

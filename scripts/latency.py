@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, ".")
 os.environ["SOAP_ENGINE_ONLY_CLASS"] = "0"
-os.environ["SOAP_ENGINE_PROFILE"] = "1"
+os.environ.setdefault("SOAP_ENGINE_PROFILE", "1")
 import numpy as np
 import bench
 from soap_amd.core import halo_tasks

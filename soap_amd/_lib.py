@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsoap_engine.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 NTYPES = 4
 
 
@@ -30,6 +30,9 @@ class EngineConfig(C.Structure):
         ("softening", C.c_double * NTYPES),
         ("n_workgroups", C.c_int32),
         ("slab_capacity", C.c_int32),
+        ("G_phys", C.c_double),
+        ("hubble", C.c_double),
+        ("rdot_omega", C.c_double),
     ]
 
 
@@ -44,7 +47,7 @@ class CalcDesc(C.Structure):
         ("virial_definition", C.c_int32),
         ("filter_limit", C.c_int32),
         ("filter_types", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 

@@ -72,6 +72,9 @@ def make_engine(cellgrid, device=0, **kw) -> Engine:
         mpc20=cellgrid.mpc_to_comoving(20.0),
         a=cellgrid.a,
         mpc=1000.0 * cellgrid.kpc,
+        G_phys=cellgrid.G,
+        hubble=cellgrid.H,
+        rdot_omega=2 * cellgrid.Omega_g + (3 / 2) * cellgrid.Omega_m,
         device=device,
         **kw,
     )

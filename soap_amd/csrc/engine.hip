@@ -111,6 +111,7 @@ struct RunParams {
     SlabDev slab;
     HaloDev halo;
     double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
+    double G_phys, hubble, rdot_omega;   // pseudo-evolution term of the shell flow rates (soap_engine_config)
     int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
     double first_factor;   // first sorted superset reaches first_factor * search_radius
     int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
@@ -1144,6 +1145,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.halo.status = h->d_status; P.halo.stats = h->d_stats; P.halo.todo = nullptr; P.halo.n_todo = 0;
     P.boxsize = h->cfg.boxsize; P.G_eff = h->cfg.G_eff; P.nu_density = h->cfg.nu_density; P.mpc20 = h->cfg.mpc20;
     P.a = h->cfg.a; P.mpc = h->cfg.mpc;
+    P.G_phys = h->cfg.G_phys; P.hubble = h->cfg.hubble; P.rdot_omega = h->cfg.rdot_omega;
     { const char *e = getenv("SOAP_ENGINE_LITERAL"); P.literal = (e && e[0] == '1') ? 1 : 0; }
     // radius the loop is expected to end at, in units of the catalogue search radius: a 5xR500 multiple
     // needs ~3.3-4 R200, density thresholds down to 50 rho_crit ~2 R200 (halo_tasks.py:184-187 steps of 1.2)

@@ -31,7 +31,8 @@ enum {
     SOC_com_gas = 26, SOC_com_star = 29, SOC_vcom_gas = 32, SOC_vcom_star = 35,
     SOC_Lgas = 38, SOC_Lstar = 41, SOC_Lbaryons = 44,
     SOC_Nnu = 47, SOC_Mnu, SOC_MnuNS,   // neutrino particles inside the sphere
-    SOC_NCOLS = 50
+    SOC_flow = 50,                      // dark matter mass flow rate: inflow at 0.1 / 0.3 / 1 R_SO, outflow at the same
+    SOC_NCOLS = 56
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {

@@ -71,7 +71,8 @@ class Engine:
     """One GPU's halo-property engine (one handle = one chunk at a time)."""
 
     def __init__(self, boxsize, G_eff, softening, nu_density=0.0, mpc20=float("inf"),
-                 a=1.0, mpc=1.0, device=0, n_workgroups=0, slab_capacity=0):  # fmt: skip
+                 a=1.0, mpc=1.0, device=0, n_workgroups=0, slab_capacity=0,
+                 G_phys=0.0, hubble=0.0, rdot_omega=0.0):  # fmt: skip
         self._lib = _lib.load()
         cfg = EngineConfig()
         cfg.abi_version = _lib.ABI_VERSION
@@ -86,6 +87,9 @@ class Engine:
             cfg.softening[i] = float(softening[i])
         cfg.n_workgroups = int(n_workgroups)
         cfg.slab_capacity = int(slab_capacity)
+        cfg.G_phys = float(G_phys)
+        cfg.hubble = float(hubble)
+        cfg.rdot_omega = float(rdot_omega)
         self._h = C.c_void_p()
         self._check(self._lib.soap_engine_create(C.byref(cfg), C.byref(self._h)))
         self.n_halo = 0

@@ -13,6 +13,8 @@ CALC_SO_MULTIPLE = 3
 CALC_APERTURE_INCL = 4
 CALC_APERTURE_EXCL = 5
 CALC_PROJECTED = 6
+# soap_calc_desc.flags
+CALC_FLAG_DM_FLOW = 1
 
 SUBHALO_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -34,6 +36,7 @@ SO_COLS = {
     "com_gas": (26, 3), "com_star": (29, 3), "vcom_gas": (32, 3), "vcom_star": (35, 3),
     "Lgas": (38, 3), "Lstar": (41, 3), "Lbaryons": (44, 3),
     "Nnu": (47, 1), "Mnu": (48, 1), "MnuNS": (49, 1),
+    "DarkMatterMassFlowRate": (50, 6),
 }  # fmt: skip
 APERTURE_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -55,9 +58,9 @@ PROJECTED_NCOLS = 25
 
 NCOLS = {
     CALC_SUBHALO: 58,
-    CALC_SO_DENSITY: 50,
-    CALC_SO_PHYSICAL: 50,
-    CALC_SO_MULTIPLE: 50,
+    CALC_SO_DENSITY: 56,
+    CALC_SO_PHYSICAL: 56,
+    CALC_SO_MULTIPLE: 56,
     CALC_APERTURE_INCL: 57,
     CALC_APERTURE_EXCL: 57,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,

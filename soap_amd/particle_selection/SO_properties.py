@@ -18,7 +18,7 @@ class SOProperties(HaloProperty):
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
-        "Nnu", "Mnu", "MnuNS",
+        "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate",
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, recently_heated_gas_filter, category_filter,
@@ -83,6 +83,10 @@ class SOProperties(HaloProperty):
         d.reference_density = self.reference_density
         d.radius = self.cellgrid.mpc_to_comoving(self.physical_radius_mpc)
         d.virial_definition = 1 if self.virial_definition else 0
+        # DarkMatterMassFlowRate is only defined for the virial definitions (SO_properties.py:2923-2924); when it
+        # is wanted the calculation needs the sphere out to 1.05 R_SO (:2849-2850)
+        if self.virial_definition and self.kind == layout.CALC_SO_DENSITY and "DarkMatterMassFlowRate" in self.enabled_properties():
+            d.flags |= layout.CALC_FLAG_DM_FLOW
         return d
 
 

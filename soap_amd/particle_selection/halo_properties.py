@@ -60,6 +60,7 @@ class HaloProperty:
         d.physical_radius_mpc = self.cellgrid.mpc_to_comoving(self.physical_radius_mpc)
         d.prev_radius = 0.0
         d.virial_definition = 0
+        d.flags = 0
         limit, mask = (0, 0)
         if self.category_filter is not None:
             limit, mask = self.category_filter.engine_filter(self.halo_filter)

@@ -35,6 +35,8 @@ class SnapshotScalars:
     comoving_softening: float = 0.0446
     max_physical_softening: float = 0.0114
     nu_density: float = 0.0  # physical code density of the neutrino background
+    H: float = 79.60499176  # Hubble rate at this redshift, 1 / code time ("H [internal units]")
+    Omega_g: float = 5.33243487e-05  # radiation density parameter (flow rates, SO_properties.py:3446-3451)
 
     @property
     def z(self):

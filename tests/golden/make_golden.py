@@ -228,7 +228,8 @@ def main():
                 "Masses": rng_nu.uniform(0.01, 0.05, n_nu), "Weights": rng_nu.normal(0.0, 0.5, n_nu),
             }  # fmt: skip
             nu_density = 0.4
-        cosmology = {"nu_density": U(nu_density)}
+        # H (1 / code time), Omega_g, Omega_m: the flow-rate terms (SO_properties.py:3446-3451); dummy snapshot values
+        cosmology = {"nu_density": U(nu_density), "H": U(79.60499176), "Omega_g": 5.33243487e-05, "Omega_m": 0.304611}
         udata = {pt: {k: U(v) for k, v in d.items()} for pt, d in data.items()}
         input_halo = {"cofp": U(centre), "index": 1, "is_central": 1}
         types_present = [f"PartType{t}" for t in (0, 1, 4, 5) if f"PartType{t}" in data]
@@ -264,6 +265,24 @@ def main():
                          "Nnu", "Mnu", "MnuNS"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
+            # dark matter mass flow rates through the three shells (SO_properties.py:2816-2932); the outer shell
+            # may reach beyond the search radius
+            case[f"{tag}/search_radius"] = np.array(2 * rmax)
+            try:
+                val = pp.DarkMatterMassFlowRate
+                case[f"{tag}/flow_status"] = np.array(0)
+                case[f"{tag}/DarkMatterMassFlowRate"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
+            except SearchRadiusTooSmallError:
+                case[f"{tag}/flow_status"] = np.array(1)
+            # the same sphere with a search radius just short of the outer shell's edge (1.05 R_SO)
+            pp2 = SO.SOParticleData(input_halo, udata, types_present, None, None, DS, None, soft, virial,
+                                    U(1.04 * float(pp.r)), cosmology, U(boxsize))
+            pp2.compute_SO_radius_and_mass(U(rho) if rho > 0 else 0.0, U(rphys))
+            try:
+                val = pp2.DarkMatterMassFlowRate
+                case[f"{tag}/flow_status_short"] = np.array(0)
+            except SearchRadiusTooSmallError:
+                case[f"{tag}/flow_status_short"] = np.array(1)
         # apertures
         for tag, incl in (("APi", True), ("APe", False)):
             rap = 0.5 * rmax
@@ -305,6 +324,7 @@ def main():
     flat["G"] = np.array(G)
     flat["softening"] = np.array(0.0114)
     flat["boxsize"] = np.array(boxsize)
+    flat["H"] = np.array(79.60499176); flat["Omega_g"] = np.array(5.33243487e-05); flat["Omega_m"] = np.array(0.304611)
 
     for name, d in out.items():
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **d)

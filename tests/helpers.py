@@ -18,7 +18,7 @@ def oracle_units(sc: SnapshotScalars) -> ho.Units:
         a=sc.a, boxsize=sc.boxsize, critical_density=sc.critical_density,
         mean_density=sc.mean_density, kpc=sc.kpc, G=sc.G,
         softening={0: soft, 1: soft, 4: soft, 5: soft},
-        nu_density=sc.nu_density, virBN98=sc.virBN98,
+        nu_density=sc.nu_density, virBN98=sc.virBN98, H=sc.H, Omega_g=sc.Omega_g, Omega_m=sc.Omega_m,
     )  # fmt: skip
 
 

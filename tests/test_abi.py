@@ -52,10 +52,26 @@ def test_layout_matches_library(built_library):
         assert re.search(rf"{name}\s*=\s*{val}\b", txt)
 
 
-def test_struct_sizes_match_header():
-    # soap_engine_config: 2*int32 + 6*double + 4*double + 2*int32 ; soap_calc_desc: 2*int32 + 4*double + 4*int32
-    assert C.sizeof(_lib.EngineConfig) == 8 + 6 * 8 + 4 * 8 + 8
-    assert C.sizeof(_lib.CalcDesc) == 8 + 4 * 8 + 16
+def test_struct_sizes_match_header(tmp_path):
+    """The ctypes mirrors against the header itself: a C program compiled from include/soap_engine.h prints
+    the size and every field offset of both structs."""
+    import subprocess
+
+    structs = {"soap_engine_config": _lib.EngineConfig, "soap_calc_desc": _lib.CalcDesc}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "soap_engine.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_no_gpu_means_loud_failure(built_library):

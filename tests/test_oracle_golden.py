@@ -78,8 +78,9 @@ def test_kinematic_helpers_match_reference():
 
 def _units(g):
     soft = float(g["softening"])
+    cosmo = {k: float(g[k]) for k in ("H", "Omega_g", "Omega_m") if k in g.files}
     return ho.Units(a=1.0, boxsize=float(g["boxsize"]), critical_density=1.0, mean_density=1.0,
-                    kpc=1.0e-3, G=float(g["G"]), softening={0: soft, 1: soft, 4: soft, 5: soft})  # fmt: skip
+                    kpc=1.0e-3, G=float(g["G"]), softening={0: soft, 1: soft, 4: soft, 5: soft}, **cosmo)  # fmt: skip
 
 
 def _case(g, i):
@@ -118,7 +119,7 @@ def test_particle_data_classes_match_reference():
     reference, property by property, on random single- and multi-type halos."""
     g = np.load(os.path.join(GOLD, "particle_data_classes.npz"))
     u0 = _units(g)
-    n_so = n_ap = n_nu = 0
+    n_so = n_ap = n_nu = n_flow = n_short = 0
     for i in range(int(g["ncases"])):
         c, data = _case(g, i)
         u = dataclasses.replace(u0, nu_density=float(c["nu_density"]))
@@ -141,11 +142,22 @@ def test_particle_data_classes_match_reference():
                 continue  # SearchRadiusTooSmall in the reference: scheduler path, tested elsewhere
             if st == 2:
                 continue  # reference crashes (documented divergence)
-            out = so._calculate(input_halo, None, data)
+            out = so._calculate(input_halo, float(c[f"{tag}/search_radius"]) if bool(c[f"{tag}/exists"]) else None, data)
             if not bool(c[f"{tag}/exists"]):
                 assert out == {}
                 continue
             n_so += 1
+            # dark matter mass flow rates: values, and the SearchRadiusTooSmallError of the outer shell
+            assert int(c[f"{tag}/flow_status"]) == 0
+            _check(tag, out, c, ["DarkMatterMassFlowRate"])
+            n_flow += int(np.count_nonzero(out.get("DarkMatterMassFlowRate", 0)) > 0)
+            short = 1.04 * float(c[f"{tag}/r"])
+            if int(c[f"{tag}/flow_status_short"]) == 1:
+                with pytest.raises(ho.SearchRadiusTooSmallError):
+                    so._calculate(input_halo, short, data)
+                n_short += 1
+            else:
+                so._calculate(input_halo, short, data)
             _check(tag, out, c, ["r", "Mtot", "com", "vcom", "Vmax_soft", "R_vmax_soft", "spin_parameter",
                                  "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar",
                                  "Nbh", "Mgas", "Mstar", "Mbh_dynamical"])  # fmt: skip
@@ -199,4 +211,4 @@ def test_particle_data_classes_match_reference():
                                                 "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
                                                 "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
                                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
-    assert n_so > 20 and n_ap > 40 and n_nu > 8
+    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20

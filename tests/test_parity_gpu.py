@@ -803,3 +803,52 @@ def test_neutrino_particles_in_the_SO_profile(built_library, engine_kw):
         nnu += int(helpers.engine_value(results[j], "SO/200_mean", "Nnu")[0])
     assert nnu > 100
     engine.close()
+
+
+class _FlowRateOff:
+    """Parameter-file stand-in that disables DarkMatterMassFlowRate (core/parameter_file.py:85-154)."""
+
+    def get_property_filters(self, base_halo_type, names):
+        return {n: (False if n == "DarkMatterMassFlowRate" else "basic") for n in names}
+
+
+def test_dark_matter_mass_flow_rates(built_library):
+    """DarkMatterMassFlowRate (SO_properties.py:2816-2932): three shells per virial SO, inflow and outflow;
+    the outer shell reaches 1.05 R_SO, so the calculation may ask for a larger sphere than the SO itself."""
+    sc, data, halos = make_chunk(250000, 120, seed=21)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "200_mean": {"value": 200.0, "type": "mean"},
+               "BN98": {"value": 0.0, "type": "BN98"}, "500_crit": {"value": 500.0, "type": "crit"}}  # fmt: skip
+    props = chp.build_halo_prop_list(sc, cf, so_vars, {})
+    assert [p.calc_desc(props, i).flags for i, p in enumerate(props)] == [0, 1, 1, 1, 0]
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, {})
+    assert np.array_equal(ha["done"], ha_ref["done"])
+    done_rows = np.flatnonzero(ha["done"] == 1)
+    n_flow = 0
+    for j, row in enumerate(done_rows):
+        compare_halo(ref[row], results[j], sc)
+        for grp in ("SO/200_crit", "SO/200_mean", "SO/BN98"):
+            fl = helpers.engine_value(results[j], grp, "DarkMatterMassFlowRate")
+            assert fl.shape == (6,) and np.all(fl >= 0)
+            n_flow += int(np.count_nonzero(fl) == 6)
+        assert np.all(helpers.engine_value(results[j], "SO/500_crit", "DarkMatterMassFlowRate") == 0)   # not a virial definition
+    assert n_flow > 50
+    raw = out[4]
+    n_loop = raw["stats"][raw["status"] == 0][:, 0].copy()
+    assert np.array_equal(n_loop, [s["n_loop"] for s in stats])
+    engine.close()
+    # with the property switched off in the parameter file the SOs alone decide the radius: no halo needs more
+    # rounds, some need fewer, and every other column is unchanged
+    props_off = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_FlowRateOff())
+    assert all(p.calc_desc(props_off, i).flags == 0 for i, p in enumerate(props_off))
+    engine, ha2, results2, out2 = _run_engine(sc, data_np, halos_np, props_off)
+    raw2 = out2[4]
+    n_loop2 = raw2["stats"][raw2["status"] == 0][:, 0]
+    if np.array_equal(ha["done"], ha2["done"]):
+        assert np.all(n_loop2 <= n_loop) and np.any(n_loop2 < n_loop)
+    for j in range(min(len(results), len(results2))):
+        assert "SO/200_crit/DarkMatterMassFlowRate" not in results2[j]
+        assert np.array_equal(results2[j]["SO/200_crit/SORadius"][4], results[j]["SO/200_crit/SORadius"][4])
+    engine.close()
