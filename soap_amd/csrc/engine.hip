@@ -367,9 +367,11 @@ struct MeshGeom {
     int res;
 };
 
-// cell index of every particle + histogram (shared_mesh.py:69-80)
+// cell index of every particle + histogram (shared_mesh.py:69-80).  The histogram's atomic add returns the
+// number of particles that entered the cell before: that is the particle's rank inside its cell, so the
+// placement pass needs no second round of atomics.
 __global__ void k_cellid(const double *pos, long long n, MeshGeom g, unsigned *cell,
-                         unsigned *count) {
+                         unsigned *count, unsigned *rank) {
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
          i += (long long)gridDim.x * BLK) {
         int c[3];
@@ -384,7 +386,7 @@ __global__ void k_cellid(const double *pos, long long n, MeshGeom g, unsigned *c
         unsigned id = (unsigned)c[0] + (unsigned)g.res * (unsigned)c[1] +
                       (unsigned)g.res * (unsigned)g.res * (unsigned)c[2];
         cell[i] = id;
-        (void)wave_agg_inc<false>(count, id, true);
+        rank[i] = wave_agg_inc<true>(count, id, true);
     }
 }
 
@@ -448,28 +450,20 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_n;
 }
 
-// place particle i at its cell's next free position (order inside a cell is arbitrary: it only
-// feeds candidate streaming; everything order-sensitive happens after the radial sort)
-__global__ void k_scatter(const unsigned *cell, long long n, const unsigned *offset,
-                          unsigned *cursor, unsigned *sort_idx) {
+// Placement: particle i goes to slot offset[cell] + rank of its cell (order inside a cell is arbitrary: it only
+// feeds candidate streaming; everything order-sensitive happens after the radial sort) and its position is
+// written there (AoS input read in order -> SoA output in cell order), so no second pass has to gather the
+// coordinates back through sort_idx.  Velocities, masses and ids stay where the caller put them: only
+// selected particles ever need them, and those are gathered through `orig` when a halo's slab is built.
+__global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
+                              unsigned *sort_idx, const double *pos, double *x, double *y, double *z) {
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
          i += (long long)gridDim.x * BLK) {
-        unsigned c = cell[i];
-        unsigned r = wave_agg_inc<true>(cursor, c, true);
-        sort_idx[offset[c] + r] = (unsigned)i;
-    }
-}
-
-// physical reorder of the coordinates into cell order (AoS input -> SoA output).  Velocities, masses and
-// ids stay where the caller put them: only selected particles ever need them, and those are gathered
-// through `orig` when a halo's slab is built.
-__global__ void k_reorder(const unsigned *sort_idx, long long n, const double *pos, double *x, double *y, double *z) {
-    for (long long p = blockIdx.x * (long long)BLK + threadIdx.x; p < n;
-         p += (long long)gridDim.x * BLK) {
-        long long i = sort_idx[p];
-        x[p] = pos[3 * i];
-        y[p] = pos[3 * i + 1];
-        z[p] = pos[3 * i + 2];
+        const unsigned c = cell[i];
+        const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+        const long long p = (long long)offset[c] + rank[i];
+        sort_idx[p] = (unsigned)i;
+        x[p] = px; y[p] = py; z[p] = pz;
     }
 }
 
@@ -983,28 +977,26 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     T.grnr64 = grnr_bytes == 8;
     const long long ncell = (long long)resolution * resolution * resolution;
 
-    unsigned *d_cell, *d_count, *d_cursor, *d_sortidx, *d_tilesum;
+    unsigned *d_cell, *d_count, *d_rank, *d_sortidx, *d_tilesum;
     HIPCHECK(pool.alloc((void **)&d_cell, (size_t)n * 4));
     HIPCHECK(pool.alloc((void **)&d_count, (size_t)ncell * 4));
-    HIPCHECK(pool.alloc((void **)&d_cursor, (size_t)ncell * 4));
+    HIPCHECK(pool.alloc((void **)&d_rank, (size_t)n * 4));
     HIPCHECK(pool.alloc((void **)&d_sortidx, (size_t)n * 4));
     HIPCHECK(pool.alloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
     HIPCHECK(hipMemsetAsync(d_count, 0, (size_t)ncell * 4, st));
-    HIPCHECK(hipMemsetAsync(d_cursor, 0, (size_t)ncell * 4, st));
     MeshGeom g;
     for (int d = 0; d < 3; d++) { g.pos_min[d] = T.pos_min[d]; g.cell_size[d] = T.cell_size[d]; }
     g.res = resolution;
     int grid = (int)std::min<long long>((n + BLK - 1) / BLK, 256 * 8);
-    hipLaunchKernelGGL(k_cellid, dim3(grid), dim3(BLK), 0, st, dpos, (long long)n, g, d_cell, d_count);
+    hipLaunchKernelGGL(k_cellid, dim3(grid), dim3(BLK), 0, st, dpos, (long long)n, g, d_cell, d_count, d_rank);
     long long ntiles = (ncell + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHECK(pool.alloc((void **)&d_tilesum, (size_t)ntiles * 4));
     hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, d_count, ncell, T.cell_offset, d_tilesum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.cell_offset, ncell, d_tilesum, (unsigned)n);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(BLK), 0, st, d_cell, (long long)n, T.cell_offset, d_cursor, d_sortidx);
     HIPCHECK(hipEventRecord(h->ev1, st));
 
-    // reorder into cell order
+    // placement + coordinates into cell order
     double **dp[] = {&T.x, &T.y, &T.z};
     for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
     T.vel = dvel; T.mass = dmass; T.fof = dfof;
@@ -1021,7 +1013,8 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     }
     hipEvent_t ev2;
     HIPCHECK(hipEventCreate(&ev2));
-    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLK), 0, st, d_sortidx, (long long)n, dpos, T.x, T.y, T.z);
+    hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset, d_sortidx,
+                       dpos, T.x, T.y, T.z);
     HIPCHECK(hipEventRecord(ev2, st));
     HIPCHECK(hipStreamSynchronize(st));
     hipError_t le = hipGetLastError();
@@ -1034,7 +1027,7 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     h->ms_reorder = ms2;
     T.orig = d_sortidx;   // original index of the particle now at position p
     pool.release(d_cell, (size_t)n * 4); pool.release(d_count, (size_t)ncell * 4);
-    pool.release(d_cursor, (size_t)ncell * 4); pool.release(d_tilesum, (size_t)ntiles * 4);
+    pool.release(d_rank, (size_t)n * 4); pool.release(d_tilesum, (size_t)ntiles * 4);
     keep_payload();
     return 0;
 }
