@@ -99,9 +99,11 @@ typedef struct soap_calc_desc {
 
 /* soap_calc_desc.flags */
 enum {
-    SOAP_CALC_FLAG_DM_FLOW = 1     /* SO_DENSITY with a virial definition: DarkMatterMassFlowRate is wanted
+    SOAP_CALC_FLAG_DM_FLOW = 1,    /* SO_DENSITY with a virial definition: DarkMatterMassFlowRate is wanted
                                       (SO_properties.py:2919-2932); the outer shell reaches 1.05 R_SO, beyond
                                       the search radius the calculation raises SearchRadiusTooSmallError */
+    SOAP_CALC_FLAG_ROTATION = 2    /* gas / star / baryon kappa_corot and disc-to-total fractions are wanted
+                                      (kinematic_properties.py:266-425): one more pass over the selection */
 };
 
 /* per-halo status column */

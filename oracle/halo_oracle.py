@@ -487,6 +487,12 @@ SCHEMA = {
     "HalfMassRadiusGas": (1, np.float32),
     "HalfMassRadiusStar": (1, np.float32),
     "HalfMassRadiusBaryon": (1, np.float32),
+    # ordered-rotation diagnostics (property_table.py:819-841, :3794-3835)
+    "kappa_corot_gas": (1, np.float32),
+    "kappa_corot_star": (1, np.float32),
+    "kappa_corot_baryons": (1, np.float32),
+    "DtoTgas": (1, np.float32),
+    "DtoTstar": (1, np.float32),
     # neutrino particles inside an SO (property_table.py: NumberOfNeutrinoParticles, RawNeutrinoMass,
     # NoiseSuppressedNeutrinoMass)
     "Nnu": (1, np.uint32),
@@ -495,6 +501,41 @@ SCHEMA = {
     # inflow at 0.1 / 0.3 / 1 R_SO, outflow at 0.1 / 0.3 / 1 R_SO (property_table.py:3327-3342)
     "DarkMatterMassFlowRate": (6, np.float32),
 }
+
+
+def angular_momentum_and_kappa_corot(mass, position, velocity, ref_velocity, do_counterrot_mass=False):
+    """
+    get_angular_momentum_and_kappa_corot_weighted without weights (kinematic_properties.py:266-425, called
+    through get_angular_momentum_and_kappa_corot_mass_weighted :428-456): total angular momentum about
+    `ref_velocity`, kappa_corot (Correa et al. 2017: kinetic energy in ordered co-rotation over the total
+    kinetic energy) and optionally the mass on counter-rotating orbits.  The reference keeps kappa and the
+    counter-rotating mass in float32 buffers (:360-381); fp64 values are returned here, the float32 cast happens
+    at the store.
+    """
+    prel = position
+    vrel = velocity - ref_velocity[None, :]
+    Lpart = mass[:, None] * np.cross(prel, vrel)
+    Ltot = 1 * (np.ones(1)[:, None] * Lpart).sum(axis=0)
+    Lnrm = np.linalg.norm(Ltot)
+    kappa_corot = 0.0
+    M_counterrot = 0.0
+    if Lnrm > 0.0:
+        K = 0.5 * (mass[:, None] * vrel**2).sum()
+        if K > 0.0 or do_counterrot_mass:
+            Ldir = Ltot / Lnrm
+            Li = (Lpart * Ldir[None, :]).sum(axis=1)
+        if K > 0.0:
+            r2 = prel[:, 0] ** 2 + prel[:, 1] ** 2 + prel[:, 2] ** 2
+            rdotL = (prel * Ldir[None, :]).sum(axis=1)
+            Ri2 = r2 - rdotL**2
+            mask = Ri2 == 0.0
+            Ri2[mask] = 1.0
+            Krot = 0.5 * (Li**2 / (mass * Ri2))
+            Kcorot = Krot[(~mask) & (Li > 0.0)].sum()
+            kappa_corot += Kcorot / K
+        if do_counterrot_mass:
+            M_counterrot += mass[Li < 0.0].sum()
+    return Ltot, kappa_corot, M_counterrot
 
 
 def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxsize):
@@ -518,11 +559,17 @@ def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxs
             out[f"vcom_{key}"] = vc
             out[f"L{key}"] = get_angular_momentum(mass[sel], position[sel], velocity[sel], vc)
             out[f"veldisp_matrix_{key}"] = get_velocity_dispersion_matrix(f, velocity[sel], vc)[0]
+            # compute_Lgas_props / compute_Lstar_props (aperture_properties.py:1147-1206, :1303-1422;
+            # SO_properties.py:753-790, :1032-1111; subhalo_properties.py:1150-1200, :1570-1690)
+            _, kappa, Mcr = angular_momentum_and_kappa_corot(mass[sel], position[sel], velocity[sel], vc, True)
+            out[f"kappa_corot_{key}"] = kappa
+            out[f"DtoT{key}"] = 1.0 - 2.0 * Mcr / M
     Mb = mass[bar].sum()
     if Mb != 0:
         fb = mass[bar] / Mb
         vcb = (fb[:, None] * velocity[bar]).sum(axis=0)
         out["Lbaryons"] = get_angular_momentum(mass[bar], position[bar], velocity[bar], vcb)
+        out["kappa_corot_baryons"] = angular_momentum_and_kappa_corot(mass[bar], position[bar], velocity[bar], vcb)[1]
     out["HalfMassRadiusGas"] = get_half_weight_radius(radius[gas], mass[gas], mass[gas].sum())
     out["HalfMassRadiusStar"] = get_half_weight_radius(radius[star], mass[star], mass[star].sum())
     out["HalfMassRadiusBaryon"] = get_half_weight_radius(radius[bar], mass[bar], Mb)
@@ -563,6 +610,7 @@ class SubhaloProperties:
         "HalfMassRadiusTot", "HalfMassRadiusDM", "veldisp_matrix_dm", "EncloseRadius",
         "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+        "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
     ]  # fmt: skip
 
     def __init__(self, units: Units, filters=DEFAULT_FILTERS, dmo=True):
@@ -661,7 +709,7 @@ class SOProperties:
         "r", "Mtot", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Vmax_soft", "R_vmax_soft",
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
-        "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
+        "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons", "DtoTgas", "DtoTstar",
         "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate",
     ]  # fmt: skip
 
@@ -980,6 +1028,7 @@ class ApertureProperties:
         "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
         "com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+        "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
     ]  # fmt: skip
 
     def __init__(self, units: Units, radius_kpc: float, inclusive: bool, all_radii_kpc=None,

@@ -15,7 +15,9 @@ enum {
     SH_com_star = 31, SH_Lgas = 34, SH_Lstar = 37, SH_Lbaryons = 40,
     SH_veldisp_gas = 43, SH_veldisp_star = 49,
     SH_HMR_gas = 55, SH_HMR_star, SH_HMR_baryon,
-    SH_NCOLS = 58
+    // ordered rotation: kappa_corot of gas / stars / baryons, disc-to-total fractions of gas / stars
+    SH_kappa = 58, SH_DtoT = 61,
+    SH_NCOLS = 63
 };
 // ---- SOAP_CALC_SO_* -------------------------------------------------------------
 enum {
@@ -32,7 +34,8 @@ enum {
     SOC_Lgas = 38, SOC_Lstar = 41, SOC_Lbaryons = 44,
     SOC_Nnu = 47, SOC_Mnu, SOC_MnuNS,   // neutrino particles inside the sphere
     SOC_flow = 50,                      // dark matter mass flow rate: inflow at 0.1 / 0.3 / 1 R_SO, outflow at the same
-    SOC_NCOLS = 56
+    SOC_DtoT = 56,                      // disc-to-total fractions of gas / stars
+    SOC_NCOLS = 58
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {
@@ -44,7 +47,8 @@ enum {
     AP_com_star = 27, AP_vcom_star = 30, AP_Lgas = 33, AP_Lstar = 36, AP_Lbaryons = 39,
     AP_veldisp_gas = 42, AP_veldisp_star = 48,
     AP_HMR_gas = 54, AP_HMR_star, AP_HMR_baryon,
-    AP_NCOLS = 57
+    AP_kappa = 57, AP_DtoT = 60,        // kappa_corot gas / stars / baryons, disc-to-total gas / stars
+    AP_NCOLS = 62
 };
 // ---- SOAP_CALC_PROJECTED: 3 blocks (projx, projy, projz) of PJ_NCOLS ---------------
 enum {

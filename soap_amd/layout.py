@@ -15,6 +15,7 @@ CALC_APERTURE_EXCL = 5
 CALC_PROJECTED = 6
 # soap_calc_desc.flags
 CALC_FLAG_DM_FLOW = 1
+CALC_FLAG_ROTATION = 2
 
 SUBHALO_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -26,6 +27,8 @@ SUBHALO_COLS = {
     "com_star": (31, 3), "Lgas": (34, 3), "Lstar": (37, 3), "Lbaryons": (40, 3),
     "veldisp_matrix_gas": (43, 6), "veldisp_matrix_star": (49, 6),
     "HalfMassRadiusGas": (55, 1), "HalfMassRadiusStar": (56, 1), "HalfMassRadiusBaryon": (57, 1),
+    "kappa_corot_gas": (58, 1), "kappa_corot_star": (59, 1), "kappa_corot_baryons": (60, 1),
+    "DtoTgas": (61, 1), "DtoTstar": (62, 1),
 }  # fmt: skip
 SO_COLS = {
     "r": (0, 1), "Mtot": (1, 1), "Ngas": (2, 1), "Ndm": (3, 1), "Nstar": (4, 1), "Nbh": (5, 1),
@@ -37,6 +40,7 @@ SO_COLS = {
     "Lgas": (38, 3), "Lstar": (41, 3), "Lbaryons": (44, 3),
     "Nnu": (47, 1), "Mnu": (48, 1), "MnuNS": (49, 1),
     "DarkMatterMassFlowRate": (50, 6),
+    "DtoTgas": (56, 1), "DtoTstar": (57, 1),
 }  # fmt: skip
 APERTURE_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -46,6 +50,8 @@ APERTURE_COLS = {
     "com_star": (27, 3), "vcom_star": (30, 3), "Lgas": (33, 3), "Lstar": (36, 3), "Lbaryons": (39, 3),
     "veldisp_matrix_gas": (42, 6), "veldisp_matrix_star": (48, 6),
     "HalfMassRadiusGas": (54, 1), "HalfMassRadiusStar": (55, 1), "HalfMassRadiusBaryon": (56, 1),
+    "kappa_corot_gas": (57, 1), "kappa_corot_star": (58, 1), "kappa_corot_baryons": (59, 1),
+    "DtoTgas": (60, 1), "DtoTstar": (61, 1),
 }  # fmt: skip
 PROJECTED_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -57,12 +63,12 @@ PROJECTED_COLS = {
 PROJECTED_NCOLS = 25
 
 NCOLS = {
-    CALC_SUBHALO: 58,
-    CALC_SO_DENSITY: 56,
-    CALC_SO_PHYSICAL: 56,
-    CALC_SO_MULTIPLE: 56,
-    CALC_APERTURE_INCL: 57,
-    CALC_APERTURE_EXCL: 57,
+    CALC_SUBHALO: 63,
+    CALC_SO_DENSITY: 58,
+    CALC_SO_PHYSICAL: 58,
+    CALC_SO_MULTIPLE: 58,
+    CALC_APERTURE_INCL: 62,
+    CALC_APERTURE_EXCL: 62,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,
 }
 

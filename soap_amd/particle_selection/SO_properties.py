@@ -18,7 +18,7 @@ class SOProperties(HaloProperty):
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
-        "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate",
+        "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate", "DtoTgas", "DtoTstar",
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, recently_heated_gas_filter, category_filter,

@@ -18,6 +18,9 @@ from .._lib import CalcDesc
 from ..property_table import full_property_list, stored_value
 
 
+_ROTATION_KEYS = ("kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar")
+
+
 class SearchRadiusTooSmallError(Exception):
     pass
 
@@ -66,6 +69,10 @@ class HaloProperty:
             limit, mask = self.category_filter.engine_filter(self.halo_filter)
         d.filter_limit = limit
         d.filter_types = mask
+        # kappa_corot / disc-to-total fractions need a pass of their own over the selection
+        # (kinematic_properties.py:266-425): only when one of them is wanted
+        if any(k in _ROTATION_KEYS for k in self.enabled_properties()):
+            d.flags |= layout.CALC_FLAG_ROTATION
         return d
 
     # ---- properties enabled for this run --------------------------------------------

@@ -82,6 +82,11 @@ full_property_list = {
     "Nnu": Property("NumberOfNeutrinoParticles", 1, np.uint32, "dimensionless", True, None, True, 0, "Number of neutrino particles."),
     "Mnu": Property("RawNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Total mass of the neutrino particles, without their weights."),
     "MnuNS": Property("NoiseSuppressedNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Weighted neutrino particle mass plus the mean neutrino density times the SO volume."),
+    "kappa_corot_gas": Property("KappaCorotGas", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the gas in ordered co-rotation (Correa et al. 2017)."),
+    "kappa_corot_star": Property("KappaCorotStars", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the stars in ordered co-rotation."),
+    "kappa_corot_baryons": Property("KappaCorotBaryons", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of gas and stars in ordered co-rotation."),
+    "DtoTgas": Property("DiscToTotalGasMassFraction", 1, np.float32, "dimensionless", True, None, False, 0, "Fraction of the gas mass in the disc: 1 - 2 * counter-rotating mass fraction."),
+    "DtoTstar": Property("DiscToTotalStellarMassFraction", 1, np.float32, "dimensionless", True, None, False, 0, "Fraction of the stellar mass in the disc: 1 - 2 * counter-rotating mass fraction."),
     "DarkMatterMassFlowRate": Property("DarkMatterMassFlowRate", 6, np.float32, "snap_mass/snap_time", True, 0, True, -1, "Mass flow rate of dark matter particles through spherical shells. Contains 6 entries: inflow rate at 0.1R, 0.3R, R, outflow rate at 0.1R, 0.3R, R."),
     "HalfMassRadiusBaryon": Property("HalfMassRadiusBaryons", 1, np.float32, _Lc, False, 1, False, 0, "Baryonic (gas and stars) half mass radius."),
 }  # fmt: skip

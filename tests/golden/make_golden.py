@@ -262,7 +262,7 @@ def main():
                          "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar", "Nbh",
                          "Mgas", "Mstar", "Mbh_dynamical", "concentration_unsoft", "concentration_soft",
                          "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
-                         "Nnu", "Mnu", "MnuNS"]:
+                         "Nnu", "Mnu", "MnuNS", "DtoTgas", "DtoTstar"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
             # dark matter mass flow rates through the three shells (SO_properties.py:2816-2932); the outer shell
@@ -292,7 +292,8 @@ def main():
             for name in ["Mtot", "Mdm", "Mgas", "Mstar", "Mbh_dynamical", "Ndm", "Ngas", "Nstar", "Nbh", "com",
                          "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",
                          "com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas",
-                         "veldisp_matrix_star", "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
+                         "veldisp_matrix_star", "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+                         "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # bound subhalo
@@ -301,7 +302,8 @@ def main():
                      "Ldm", "veldisp_matrix_dm", "Vmax_unsoft", "R_vmax_unsoft", "Vmax_soft", "spin_parameter",
                      "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius",
                      "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
-                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
+                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+                     "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar"]:
             val = getattr(pp, name)
             case[f"SH/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # projected

@@ -114,12 +114,30 @@ def _check(tag, out, c, keys, exact=True):
             assert np.allclose(got, want, rtol=1e-6, atol=0), (tag, key, got, want)
 
 
+ROT_KEYS = ("kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar")
+
+
+def _check_rotation(tag, out, c, keys=ROT_KEYS):
+    """kappa_corot and the disc fractions pass through float32 buffers in the reference
+    (kinematic_properties.py:360-381): equal to float32 precision, absolute for the disc fraction (1 - 2 M_cr / M)."""
+    n = 0
+    for key in keys:
+        want = c[f"{tag}/{key}"]
+        got = out.get(key)
+        if np.all(np.isnan(want)):
+            assert got is None or np.all(np.asarray(got) == 0), (tag, key, got)
+            continue
+        assert abs(float(np.asarray(got).reshape(-1)[0]) - float(want)) <= 2e-7 * max(1.0, abs(float(want))), (tag, key, got, want)
+        n += 1
+    return n
+
+
 def test_particle_data_classes_match_reference():
     """SOParticleData / ApertureParticleData / SubhaloParticleData / projected classes of the
     reference, property by property, on random single- and multi-type halos."""
     g = np.load(os.path.join(GOLD, "particle_data_classes.npz"))
     u0 = _units(g)
-    n_so = n_ap = n_nu = n_flow = n_short = 0
+    n_so = n_ap = n_nu = n_flow = n_short = n_rot = 0
     for i in range(int(g["ncases"])):
         c, data = _case(g, i)
         u = dataclasses.replace(u0, nu_density=float(c["nu_density"]))
@@ -163,6 +181,7 @@ def test_particle_data_classes_match_reference():
                                  "Nbh", "Mgas", "Mstar", "Mbh_dynamical"])  # fmt: skip
             _check(tag, out, c, ["com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"])
             _check(tag, out, c, ["Nnu", "Mnu", "MnuNS"])
+            n_rot += _check_rotation(tag, out, c, ("DtoTgas", "DtoTstar"))
             n_nu += int(6 in data and out.get("Nnu", 0) > 0)
             # concentration: the reference rounds to float32 (SO_properties.py:2735)
             _check(tag, out, c, ["concentration_unsoft", "concentration_soft"], exact=False)
@@ -176,6 +195,7 @@ def test_particle_data_classes_match_reference():
                                  "R_vmax_soft"])  # fmt: skip
             _check(tag, out, c, ["com_star", "vcom_star", "Lgas", "Lstar", "Lbaryons", "HalfMassRadiusGas",
                                  "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
+            n_rot += _check_rotation(tag, out, c)
             for vk in ("veldisp_matrix_dm", "veldisp_matrix_gas", "veldisp_matrix_star"):
                 want = c[f"{tag}/{vk}"]
                 if not np.all(np.isnan(want)):   # the reference's result buffer is float32
@@ -197,6 +217,7 @@ def test_particle_data_classes_match_reference():
                 assert np.all(got == 0)
             else:
                 assert np.allclose(got.reshape(want.shape), want, rtol=RTOL, atol=0), (i, key, got, want)
+        n_rot += _check_rotation("SH", out, c)
         for vk in ("veldisp_matrix_dm", "veldisp_matrix_gas", "veldisp_matrix_star"):
             want = c[f"SH/{vk}"]
             if not np.all(np.isnan(want)):
@@ -211,4 +232,4 @@ def test_particle_data_classes_match_reference():
                                                 "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
                                                 "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
                                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
-    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20
+    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20 and n_rot > 150

@@ -69,7 +69,7 @@ def _abs_scale(key, M, vscale):
         return vscale**2
     if key.startswith("vcom") or key.startswith("proj_veldisp_"):
         return vscale
-    if key.startswith("com"):
+    if key.startswith("com") or key.startswith("DtoT"):
         return 1.0
     return 0.0
 
@@ -287,6 +287,21 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
     assert nchecked > 5000
     ngas = sum(int(helpers.engine_value(r, "BoundSubhalo", "Ngas")[0]) for r in results)
     assert ngas > 0
+    # ordered rotation (kinematic_properties.py:266-425): kappa_corot in [0, 1], disc fractions in [-1, 1], and
+    # they are really computed (not all zero / one) in every class that carries them
+    nrot = 0
+    for r in results:
+        for grp in ("BoundSubhalo", "InclusiveSphere/100kpc", "ExclusiveSphere/30kpc"):
+            for key in ("kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons"):
+                k = float(helpers.engine_value(r, grp, key)[0])
+                assert 0.0 <= k <= 1.0 + 1e-12
+                nrot += int(0.0 < k < 1.0)
+        for grp in ("BoundSubhalo", "InclusiveSphere/100kpc", "SO/200_crit"):
+            for key in ("DtoTgas", "DtoTstar"):
+                d = float(helpers.engine_value(r, grp, key)[0])
+                assert -1.0 - 1e-12 <= d <= 1.0 + 1e-12
+                nrot += int(-1.0 < d < 1.0 and d != 0.0)
+    assert nrot > 500
     engine.close()
 
 
