@@ -50,6 +50,18 @@ WORKLOADS = {
 }  # fmt: skip
 
 
+class _NamedPropertySet:
+    """Parameter-file stand-in (core/parameter_file.py:85-154): the benchmark configurations name the SO /
+    aperture property set of the north star (masses, centres, angular momenta, dispersion tensors, half-mass
+    radii, v_max, concentration, flow rates); the inertia tensors (up to 20 passes per tensor over
+    the search sphere) are switched off, for the engine and for the CPU baseline alike."""
+
+    def get_property_filters(self, base_halo_type, names):
+        if os.environ.get("BENCH_INERTIA") == "1":   # diagnostic: the same configurations with the tensors on
+            return {n: "basic" for n in names}
+        return {n: (False if "InertiaTensor" in n else "basic") for n in names}
+
+
 def build_props(sc, wl):
     from soap_amd import compute_halo_properties as chp
     from soap_amd.core.category_filter import CategoryFilter
@@ -58,7 +70,8 @@ def build_props(sc, wl):
     so_vars = None if wl["so"] == "default" else {"200_crit": {"value": 200.0, "type": "crit"}}
     ap_vars = chp.aperture_variations(wl["apertures"]) if wl["apertures"] else {}
     pj_vars = chp.projected_variations(wl["projected"]) if wl.get("projected") else {}
-    return cf, so_vars, ap_vars, pj_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars)
+    return cf, so_vars, ap_vars, pj_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars,
+                                                                   parameters=_NamedPropertySet())
 
 
 def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
@@ -88,6 +101,7 @@ def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
     h_np = {k: v[rows].cpu().numpy() for k, v in halos.items()}
     cf, so_vars, ap_vars, pj_vars, _ = build_props(sc, wl)
     u, props = helpers.oracle_prop_list(sc, cf, so_vars, ap_vars, pj_vars)
+    ho.ENABLE_INERTIA = os.environ.get("BENCH_INERTIA") == "1"   # same property set as the engine run (_NamedPropertySet)
     npart = sum(d["Masses"].shape[0] for d in d_np.values())
     mesh = {}
     for pt, d in d_np.items():

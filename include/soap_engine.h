@@ -102,6 +102,9 @@ enum {
     SOAP_CALC_FLAG_DM_FLOW = 1,    /* SO_DENSITY with a virial definition: DarkMatterMassFlowRate is wanted
                                       (SO_properties.py:2919-2932); the outer shell reaches 1.05 R_SO, beyond
                                       the search radius the calculation raises SearchRadiusTooSmallError */
+    SOAP_CALC_FLAG_INERTIA = 4,    /* bound subhalo / SO: the eight inertia tensors of the total and the dark
+                                      matter mass are wanted (inertia_tensors.py:19-132): up to 20 passes per
+                                      tensor family over the particles of the search sphere */
     SOAP_CALC_FLAG_ROTATION = 2    /* gas / star / baryon kappa_corot and disc-to-total fractions are wanted
                                       (kinematic_properties.py:266-425): one more pass over the selection */
 };
@@ -120,6 +123,9 @@ enum {
 /* number of fp64 output columns a calculation kind writes (fixed layout, see
  * soap_amd/layout.py which mirrors csrc/layout.h) */
 int32_t soap_engine_calc_columns(int32_t kind);
+/* columns a calculation occupies in THIS run: soap_engine_calc_columns(kind), minus the 48 inertia tensor
+ * columns at the end of the subhalo / SO blocks when SOAP_CALC_FLAG_INERTIA is not set */
+int32_t soap_engine_desc_columns(const soap_calc_desc *desc);
 
 int32_t soap_engine_abi_version(void);
 const char *soap_engine_last_error(void);

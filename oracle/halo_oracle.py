@@ -493,6 +493,12 @@ SCHEMA = {
     "kappa_corot_baryons": (1, np.float32),
     "DtoTgas": (1, np.float32),
     "DtoTstar": (1, np.float32),
+    # inertia tensors of the total and the dark matter mass (property_table.py:2724-2790 and the DarkMatter rows):
+    # xx yy zz xy xz yz
+    **{k: (6, np.float32) for k in (
+        "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
+        "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
+        "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative")},
     # neutrino particles inside an SO (property_table.py: NumberOfNeutrinoParticles, RawNeutrinoMass,
     # NoiseSuppressedNeutrinoMass)
     "Nnu": (1, np.uint32),
@@ -501,6 +507,99 @@ SCHEMA = {
     # inflow at 0.1 / 0.3 / 1 R_SO, outflow at 0.1 / 0.3 / 1 R_SO (property_table.py:3327-3342)
     "DarkMatterMassFlowRate": (6, np.float32),
 }
+
+
+INERTIA_KEYS = (
+    "TotalInertiaTensor", "TotalInertiaTensorReduced",
+    "TotalInertiaTensorNoniterative", "TotalInertiaTensorReducedNoniterative",
+    "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
+    "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+)
+
+
+def get_weighted_inertia_tensor(particle_weights, particle_positions, sphere_radius, search_radius=None,
+                                reduced=False, max_iterations=20, min_particles=20):  # fmt: skip
+    """
+    property_calculation/inertia_tensors.py:19-132.  I_ij = sum w x_i x_j / sum w over the particles inside an
+    ellipsoid that starts as the sphere of `sphere_radius` and is re-shaped from the eigenvectors / eigenvalue
+    ratios of the previous tensor (same volume), until q = sqrt(b/a) changes by less than 1e-4 or
+    `max_iterations` tensors were computed.  `reduced` divides every particle's term by |x|^2 (particles at
+    the centre, np.isclose(|x|^2, 0) in the position unit, are dropped first).  Returns the six independent
+    components (xx, yy, zz, xy, xz, yz) of the LAST tensor, or None with fewer than `min_particles`
+    particles (in total, or inside the initial sphere).  The reference works in kpc; a uniform rescaling of
+    the lengths changes neither the memberships nor the eigenvectors, so this works in the caller's unit.
+    """
+    if particle_weights.shape[0] < min_particles:
+        return None
+    if reduced:
+        norm = np.linalg.norm(particle_positions, axis=1) ** 2
+        mask = np.logical_not(np.isclose(norm, 0))
+        norm = norm[mask]
+        particle_weights = particle_weights[mask]
+        particle_positions = particle_positions[mask]
+    tol = 0.0001
+    q = 1000
+    R = sphere_radius
+    eig_val = [1, 1, 1]
+    eig_vec = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    tensor = None
+    for i_iter in range(max_iterations):
+        old_q = q
+        with np.errstate(all="ignore"):
+            q = np.sqrt(eig_val[1] / eig_val[2])
+            s = np.sqrt(eig_val[0] / eig_val[2])
+            p = np.sqrt(eig_val[0] / eig_val[1])
+            if abs((old_q - q) / q) < tol:
+                break
+            axis = R * np.array([1 * np.cbrt(s * p), 1 * np.cbrt(q / p), 1 / np.cbrt(q * s)])
+            p = np.dot(particle_positions, eig_vec) / axis
+            r = np.linalg.norm(p, axis=1)
+            if (i_iter == 0) and (np.sum(r <= 1) < min_particles):
+                return None
+            weight = particle_weights / np.sum(particle_weights[r <= 1])
+            weight[r > 1] = 0
+            if (search_radius is not None) and (np.max(R) > search_radius):
+                raise SearchRadiusTooSmallError("Inertia tensor required more particles")
+            tensor = weight[:, None, None] * particle_positions[:, :, None] * particle_positions[:, None, :]
+            if reduced:
+                tensor /= norm[:, None, None]
+            tensor = tensor.sum(axis=0)
+            eig_val, eig_vec = np.linalg.eigh(tensor)
+            eig_val = np.abs(eig_val)
+        if q == 0:
+            tensor.fill(0)
+            break
+    return np.concatenate([np.diag(tensor), tensor[np.triu_indices(3, 1)]])
+
+
+# the parameter file can switch properties off (parameter_file.py:85-154); the only switch this restatement
+# needs is the one for the inertia tensors, whose iterations dominate the run time when they are on
+ENABLE_INERTIA = True
+
+
+def inertia_tensors(out, mass, position, types, R_tot, R_dm, search_radius, has_tot, has_dm, n_inner=None):
+    """
+    The eight dark-matter-only-run tensors of a selection (SO_properties.py:620-672, :915-972;
+    subhalo_properties.py:1075-1125, :1302-1352): total mass and dark matter, iterative and within the fixed
+    sphere (`max_iterations=1`), plain and reduced.  `mass / position / types`: every particle the iterative
+    version may use (SO: members first, then the surrounding particles of the search sphere; bound subhalo:
+    the bound particles); the fixed-sphere version is handed the same arrays, since particles outside the
+    sphere get weight zero.  R_tot / R_dm: the spheres' radii.  n_inner: the fixed-sphere versions only see the
+    first n_inner particles (SO: the members, SO_properties.py:658-659, :957-958).
+    """
+    if not ENABLE_INERTIA:
+        return
+    n_inner = len(mass) if n_inner is None else n_inner
+    dm = types == 1
+    inner = np.arange(len(mass)) < n_inner
+    for name, sel, R, ok in (("Total", np.ones(len(mass), dtype=bool), R_tot, has_tot), ("DarkMatter", dm, R_dm, has_dm)):
+        if not ok:
+            continue
+        m, x = mass[sel], position[sel]
+        mi, xi = mass[sel & inner], position[sel & inner]
+        for suffix, kw in (("", {}), ("Reduced", {"reduced": True})):
+            out[f"{name}InertiaTensor{suffix}"] = get_weighted_inertia_tensor(m, x, R, search_radius=search_radius, **kw)
+            out[f"{name}InertiaTensor{suffix}Noniterative"] = get_weighted_inertia_tensor(mi, xi, R, max_iterations=1, **kw)
 
 
 def angular_momentum_and_kappa_corot(mass, position, velocity, ref_velocity, do_counterrot_mass=False):
@@ -611,6 +710,7 @@ class SubhaloProperties:
         "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
         "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
+        *INERTIA_KEYS,
     ]  # fmt: skip
 
     def __init__(self, units: Units, filters=DEFAULT_FILTERS, dmo=True):
@@ -693,6 +793,9 @@ class SubhaloProperties:
         out["HalfMassRadiusTot"] = get_half_weight_radius(radius, mass, Mtot)
         out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
         baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize)
+        # bound particles inside 10 half-mass radii, no search-radius condition (subhalo_properties.py:1075-1125, :1302-1352)
+        inertia_tensors(out, mass, position, types, 10 * out["HalfMassRadiusTot"], 10 * out["HalfMassRadiusDM"],
+                        None, Mtot != 0, M_t[1] != 0)
 
         for key in self.property_list:
             _store(halo_result, g, key, out.get(key))
@@ -710,6 +813,7 @@ class SOProperties:
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons", "DtoTgas", "DtoTstar",
+        *INERTIA_KEYS,
         "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate",
     ]  # fmt: skip
 
@@ -872,6 +976,10 @@ class SOProperties:
         N = {t: int((radius[types == t] < SO_r).sum()) for t in PTYPES}
         all_dm = types == 1   # every dark matter particle of the search sphere (flow rate through the outer shell)
         dm_all_mass, dm_all_pos, dm_all_vel = mass[all_dm], position[all_dm], velocity[all_dm]
+        # members first, then the surrounding particles (SO_properties.py:491-496, :629-630)
+        it_mass = np.concatenate([mass[sel], mass[~sel]])
+        it_pos = np.concatenate([position[sel], position[~sel]])
+        it_types = np.concatenate([types[sel], types[~sel]])
         mass = mass[sel]
         radius = radius[sel]
         position = position[sel]
@@ -936,6 +1044,8 @@ class SOProperties:
                 R1 += missed_mass * SO_r
                 R1 /= SO_r * SO_mass
                 out[key] = concentration_from_R1(R1)
+        inertia_tensors(out, it_mass, it_pos, it_types, SO_r, SO_r, search_radius, Mtotpart != 0, M_t[1] != 0,
+                        n_inner=int(sel.sum()))
         if self.virial_definition and N[1] != 0:
             # DarkMatterMassFlowRate (SO_properties.py:2919-2932): all loaded dark matter, not only r < R_SO
             out["DarkMatterMassFlowRate"] = mass_flow_rate(

@@ -56,6 +56,7 @@ SYMBOLS = {
     "soap_engine_abi_version": (C.c_int32, []),
     "soap_engine_last_error": (C.c_char_p, []),
     "soap_engine_calc_columns": (C.c_int32, [C.c_int32]),
+    "soap_engine_desc_columns": (C.c_int32, [C.POINTER(CalcDesc)]),
     "soap_engine_create": (C.c_int32, [C.POINTER(EngineConfig), C.POINTER(C.c_void_p)]),
     "soap_engine_destroy": (C.c_int32, [C.c_void_p]),
     "soap_engine_stage_particles": (

@@ -126,7 +126,7 @@ def bind_results(engine: Engine, halo_prop_list: List, raw: Dict, halo_arrays: D
     """Make the result of `process_halos(..., unpack=...)` available to `prop.calculate(input_halo, ...)`
     for every entry of halo_prop_list.  `raw` is the last element process_halos returned."""
     calcs = [hp.calc_desc(halo_prop_list, i) for i, hp in enumerate(halo_prop_list)]
-    coloff = np.concatenate([[0], np.cumsum([engine._lib.soap_engine_calc_columns(c.kind) for c in calcs])])
+    coloff = np.concatenate([[0], np.cumsum([engine.desc_columns(c) for c in calcs])])
     table = raw["table"] if raw.get("table") is not None else engine.fetch(table=True)["table"]
     index = np.asarray(halo_arrays["index"])[raw["rows"]]
     batch = BatchResult(table, raw["status"], index, coloff, halo_prop_list[0])
@@ -178,7 +178,7 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     halo_arrays["search_radius"][todo[again]] = out["search_radius"][again]
 
     if unpack:
-        coloff = np.concatenate([[0], np.cumsum([engine._lib.soap_engine_calc_columns(c.kind) for c in calcs])])
+        coloff = np.concatenate([[0], np.cumsum([engine.desc_columns(c) for c in calcs])])
         table = out["table"]
         for j in np.flatnonzero(ok):
             row = table[j]

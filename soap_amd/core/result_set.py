@@ -28,9 +28,9 @@ from .halo_tasks import _INPUT_HALO_COLUMNS   # InputHalos/* datasets every cata
 class ResultSet:
     """Named, typed columns of the halos finished so far (any number of `append_table` calls)."""
 
-    def __init__(self, halo_prop_list: List, engine_calc_columns):
+    def __init__(self, halo_prop_list: List, engine_desc_columns):
         self.props = list(halo_prop_list)
-        ncols = [int(engine_calc_columns(hp.kind)) for hp in self.props]
+        ncols = [int(engine_desc_columns(hp.calc_desc(self.props, i))) for i, hp in enumerate(self.props)]
         self.coloff = np.concatenate([[0], np.cumsum(ncols)]).astype(np.int64)
         self._chunks: Dict[str, List[np.ndarray]] = {}
         self.meta: Dict[str, Dict] = {}
@@ -140,7 +140,7 @@ def run_chunk(engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, max_pas
     """
     from . import halo_tasks
 
-    rs = ResultSet(halo_prop_list, engine._lib.soap_engine_calc_columns)
+    rs = ResultSet(halo_prop_list, engine.desc_columns)
     halo_arrays.setdefault("done", np.zeros(len(halo_arrays["index"]), dtype=np.int32))
     for _ in range(max_passes):
         if not np.any(halo_arrays["done"] == 0):

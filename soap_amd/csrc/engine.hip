@@ -541,9 +541,16 @@ struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexe
 #define GLB 4
 #define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#define GINERTIA 0
 namespace g64 {
 #include "halo_kernel.inc"
 }
+#undef GINERTIA
+#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
+namespace g64i {     // stay out of the variant every other run uses)
+#include "halo_kernel.inc"
+}
+#undef GINERTIA
 #undef GRP
 #undef GNW
 #undef GWG
@@ -561,9 +568,16 @@ namespace g64 {
 #define GLB 2
 #define GATTR __launch_bounds__(GRP, GLB)
 #define GSYNC() __syncthreads()
+#define GINERTIA 0
 namespace g256 {
 #include "halo_kernel.inc"
 }
+#undef GINERTIA
+#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
+namespace g256i {     // stay out of the variant every other run uses)
+#include "halo_kernel.inc"
+}
+#undef GINERTIA
 #undef GRP
 #undef GNW
 #undef GWG
@@ -584,9 +598,16 @@ namespace g256 {
 #define GLB (G3T == 1024 ? 4 : 2)
 #define GATTR __launch_bounds__(GRP, GLB)
 #define GSYNC() __syncthreads()
+#define GINERTIA 0
 namespace g1024 {
 #include "halo_kernel.inc"
 }
+#undef GINERTIA
+#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
+namespace g1024i {     // stay out of the variant every other run uses)
+#include "halo_kernel.inc"
+}
+#undef GINERTIA
 #undef GRP
 #undef GNW
 #undef GWG
@@ -788,6 +809,14 @@ extern "C" {
 
 int32_t soap_engine_abi_version(void) { return SOAP_ENGINE_ABI_VERSION; }
 const char *soap_engine_last_error(void) { return g_err.c_str(); }
+
+int32_t soap_engine_desc_columns(const soap_calc_desc *desc) {
+    if (!desc) return -1;
+    int32_t nc = soap_engine_calc_columns(desc->kind);
+    // the inertia tensors are the last 48 columns of the subhalo and SO blocks: only there when wanted
+    if (nc > 0 && desc->kind <= SOAP_CALC_SO_MULTIPLE && !(desc->flags & SOAP_CALC_FLAG_INERTIA)) nc -= 48;
+    return nc;
+}
 
 int32_t soap_engine_calc_columns(int32_t kind) {
     switch (kind) {
@@ -1083,8 +1112,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipSetDevice(h->cfg.device));
     std::vector<int> coloff(n_calcs);
     long long ncols = 0;
+    bool want_inertia = false;
+    for (int c = 0; c < n_calcs; c++) want_inertia = want_inertia || (calcs[c].flags & SOAP_CALC_FLAG_INERTIA);
     for (int c = 0; c < n_calcs; c++) {
-        int nc = soap_engine_calc_columns(calcs[c].kind);
+        int nc = soap_engine_desc_columns(&calcs[c]);
         if (nc < 0) return fail(-5, "unknown calculation kind");
         if (c > 0 && calcs[c].kind == SOAP_CALC_SUBHALO) return fail(-6, "only one subhalo calculation allowed");
         if (calcs[c].kind == SOAP_CALC_SO_MULTIPLE) {
@@ -1248,9 +1279,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             const RunParams *dp = h->d_params;
             HIPCHECK(hipEventRecord(C.start, cs));
             C.nh += (long long)todo[k].size();
-            if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            if (!want_inertia) {
+                if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            } else {
+                if (k == 0) hipLaunchKernelGGL(g64i::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else if (k == 1) hipLaunchKernelGGL(g256i::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else hipLaunchKernelGGL(g1024i::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+            }
             HIPCHECK(hipEventRecord(C.done, cs));
             HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         }

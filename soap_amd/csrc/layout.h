@@ -17,7 +17,10 @@ enum {
     SH_HMR_gas = 55, SH_HMR_star, SH_HMR_baryon,
     // ordered rotation: kappa_corot of gas / stars / baryons, disc-to-total fractions of gas / stars
     SH_kappa = 58, SH_DtoT = 61,
-    SH_NCOLS = 63
+    // inertia tensors (xx yy zz xy xz yz each): total {iterative, reduced, fixed sphere, reduced fixed sphere},
+    // then the same four for the dark matter
+    SH_inertia = 63,
+    SH_NCOLS = 111
 };
 // ---- SOAP_CALC_SO_* -------------------------------------------------------------
 enum {
@@ -35,7 +38,8 @@ enum {
     SOC_Nnu = 47, SOC_Mnu, SOC_MnuNS,   // neutrino particles inside the sphere
     SOC_flow = 50,                      // dark matter mass flow rate: inflow at 0.1 / 0.3 / 1 R_SO, outflow at the same
     SOC_DtoT = 56,                      // disc-to-total fractions of gas / stars
-    SOC_NCOLS = 58
+    SOC_inertia = 58,                   // eight inertia tensors, as in the bound subhalo block
+    SOC_NCOLS = 106
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {

@@ -187,6 +187,10 @@ class Engine:
         self._check(self._lib.soap_engine_run(self._h, arr, len(calcs), td))
         self.calcs = list(calcs)
 
+    def desc_columns(self, desc) -> int:
+        """Columns the calculation `desc` (a CalcDesc) occupies in the result table of a run."""
+        return int(self._lib.soap_engine_desc_columns(C.byref(desc)))
+
     @property
     def row_columns(self):
         return int(self._lib.soap_engine_row_columns(self._h))

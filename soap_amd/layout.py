@@ -16,6 +16,15 @@ CALC_PROJECTED = 6
 # soap_calc_desc.flags
 CALC_FLAG_DM_FLOW = 1
 CALC_FLAG_ROTATION = 2
+CALC_FLAG_INERTIA = 4
+
+# total / dark matter inertia tensors, in column order
+INERTIA_KEYS = (
+    "TotalInertiaTensor", "TotalInertiaTensorReduced",
+    "TotalInertiaTensorNoniterative", "TotalInertiaTensorReducedNoniterative",
+    "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
+    "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+)
 
 SUBHALO_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -29,6 +38,7 @@ SUBHALO_COLS = {
     "HalfMassRadiusGas": (55, 1), "HalfMassRadiusStar": (56, 1), "HalfMassRadiusBaryon": (57, 1),
     "kappa_corot_gas": (58, 1), "kappa_corot_star": (59, 1), "kappa_corot_baryons": (60, 1),
     "DtoTgas": (61, 1), "DtoTstar": (62, 1),
+    **{k: (63 + 6 * i, 6) for i, k in enumerate(INERTIA_KEYS)},
 }  # fmt: skip
 SO_COLS = {
     "r": (0, 1), "Mtot": (1, 1), "Ngas": (2, 1), "Ndm": (3, 1), "Nstar": (4, 1), "Nbh": (5, 1),
@@ -41,6 +51,7 @@ SO_COLS = {
     "Nnu": (47, 1), "Mnu": (48, 1), "MnuNS": (49, 1),
     "DarkMatterMassFlowRate": (50, 6),
     "DtoTgas": (56, 1), "DtoTstar": (57, 1),
+    **{k: (58 + 6 * i, 6) for i, k in enumerate(INERTIA_KEYS)},
 }  # fmt: skip
 APERTURE_COLS = {
     "Mtot": (0, 1), "Mgas": (1, 1), "Mdm": (2, 1), "Mstar": (3, 1), "Mbh_dynamical": (4, 1),
@@ -63,10 +74,10 @@ PROJECTED_COLS = {
 PROJECTED_NCOLS = 25
 
 NCOLS = {
-    CALC_SUBHALO: 63,
-    CALC_SO_DENSITY: 58,
-    CALC_SO_PHYSICAL: 58,
-    CALC_SO_MULTIPLE: 58,
+    CALC_SUBHALO: 111,
+    CALC_SO_DENSITY: 106,
+    CALC_SO_PHYSICAL: 106,
+    CALC_SO_MULTIPLE: 106,
     CALC_APERTURE_INCL: 62,
     CALC_APERTURE_EXCL: 62,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,
@@ -83,3 +94,12 @@ def columns_of(kind):
     if kind == CALC_PROJECTED:
         return PROJECTED_COLS
     raise KeyError(kind)
+
+
+def desc_columns(desc) -> int:
+    """Columns a calculation occupies in one run (mirror of soap_engine_desc_columns): the full width of its
+    kind, minus the 48 inertia tensor columns that end the subhalo / SO blocks when they are not wanted."""
+    nc = NCOLS[desc.kind]
+    if desc.kind <= CALC_SO_MULTIPLE and not (desc.flags & CALC_FLAG_INERTIA):
+        nc -= 6 * len(INERTIA_KEYS)
+    return nc

@@ -19,6 +19,7 @@ class SOProperties(HaloProperty):
         "spin_parameter", "concentration_unsoft", "concentration_soft",
         "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
         "Nnu", "Mnu", "MnuNS", "DarkMatterMassFlowRate", "DtoTgas", "DtoTstar",
+        *layout.INERTIA_KEYS,
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, recently_heated_gas_filter, category_filter,

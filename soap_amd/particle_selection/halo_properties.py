@@ -73,6 +73,9 @@ class HaloProperty:
         # (kinematic_properties.py:266-425): only when one of them is wanted
         if any(k in _ROTATION_KEYS for k in self.enabled_properties()):
             d.flags |= layout.CALC_FLAG_ROTATION
+        # inertia tensors: iterative passes over the particles of the search sphere (inertia_tensors.py:19-132)
+        if any(k in layout.INERTIA_KEYS for k in self.enabled_properties()):
+            d.flags |= layout.CALC_FLAG_INERTIA
         return d
 
     # ---- properties enabled for this run --------------------------------------------

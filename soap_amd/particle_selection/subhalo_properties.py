@@ -22,6 +22,7 @@ class SubhaloProperties(HaloProperty):
         "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
         "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
+        *layout.INERTIA_KEYS,
     ]  # fmt: skip
 
     def __init__(self, cellgrid, parameters=None, recently_heated_gas_filter=None,

@@ -82,6 +82,14 @@ full_property_list = {
     "Nnu": Property("NumberOfNeutrinoParticles", 1, np.uint32, "dimensionless", True, None, True, 0, "Number of neutrino particles."),
     "Mnu": Property("RawNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Total mass of the neutrino particles, without their weights."),
     "MnuNS": Property("NoiseSuppressedNeutrinoMass", 1, np.float32, _M, True, None, True, 0, "Weighted neutrino particle mass plus the mean neutrino density times the SO volume."),
+    "TotalInertiaTensor": Property("TotalInertiaTensor", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the total mass distribution relative to the halo centre (computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "TotalInertiaTensorReduced": Property("TotalInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the total mass distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "TotalInertiaTensorNoniterative": Property("TotalInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the total mass distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "TotalInertiaTensorReducedNoniterative": Property("TotalInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the total mass distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "DarkMatterInertiaTensor": Property("DarkMatterInertiaTensor", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "DarkMatterInertiaTensorReduced": Property("DarkMatterInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "DarkMatterInertiaTensorNoniterative": Property("DarkMatterInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "DarkMatterInertiaTensorReducedNoniterative": Property("DarkMatterInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "kappa_corot_gas": Property("KappaCorotGas", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the gas in ordered co-rotation (Correa et al. 2017)."),
     "kappa_corot_star": Property("KappaCorotStars", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the stars in ordered co-rotation."),
     "kappa_corot_baryons": Property("KappaCorotBaryons", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of gas and stars in ordered co-rotation."),

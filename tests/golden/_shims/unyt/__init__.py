@@ -81,6 +81,13 @@ class unyt_array(np.ndarray):
 
     v = value
 
+    def __getitem__(self, item):
+        # like unyt: one element of a quantity array is still a quantity (it has .to(), .units, ...)
+        res = super().__getitem__(item)
+        if isinstance(res, np.generic):
+            return np.asarray(res).view(unyt_array)
+        return res
+
     def to(self, *a, **k):
         return self
 

@@ -262,7 +262,10 @@ def main():
                          "Mfrac_satellites", "Mfrac_external", "Mdm", "Ldm", "Ndm", "Ngas", "Nstar", "Nbh",
                          "Mgas", "Mstar", "Mbh_dynamical", "concentration_unsoft", "concentration_soft",
                          "com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons",
-                         "Nnu", "Mnu", "MnuNS", "DtoTgas", "DtoTstar"]:
+                         "Nnu", "Mnu", "MnuNS", "DtoTgas", "DtoTstar",
+                         "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
+                         "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
+                         "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
             # dark matter mass flow rates through the three shells (SO_properties.py:2816-2932); the outer shell
@@ -303,7 +306,10 @@ def main():
                      "HalfMassRadiusTot", "HalfMassRadiusDM", "EncloseRadius",
                      "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
                      "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
-                     "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar"]:
+                     "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
+                     "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
+                     "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
+                     "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative"]:
             val = getattr(pp, name)
             case[f"SH/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # projected

@@ -38,6 +38,12 @@ def test_layout_matches_library(built_library):
     for kind, ncols in layout.NCOLS.items():
         assert lib.soap_engine_calc_columns(kind) == ncols
     assert lib.soap_engine_calc_columns(99) == -1
+    # per-run widths: the inertia tensor columns exist only when the calculation asks for them
+    for kind in layout.NCOLS:
+        for flags in (0, layout.CALC_FLAG_INERTIA, layout.CALC_FLAG_DM_FLOW | layout.CALC_FLAG_ROTATION):
+            d = _lib.CalcDesc()
+            d.kind, d.flags = kind, flags
+            assert lib.soap_engine_desc_columns(C.byref(d)) == layout.desc_columns(d)
     for kind in layout.NCOLS:
         cols = layout.columns_of(kind)
         width = layout.PROJECTED_NCOLS if kind == layout.CALC_PROJECTED else layout.NCOLS[kind]

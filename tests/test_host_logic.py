@@ -125,7 +125,7 @@ def test_result_set_columns_from_a_table():
     cf = CategoryFilter(dmo=False)
     props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}},
                                      chp.aperture_variations((50.0,)), projected_vars=chp.projected_variations((30.0,)))  # fmt: skip
-    rs = ResultSet(props, lambda kind: layout.NCOLS[kind])
+    rs = ResultSet(props, layout.desc_columns)
     n = 7
     rng = np.random.default_rng(3)
     table = rng.uniform(1.0, 2.0, size=(n, int(rs.coloff[-1])))

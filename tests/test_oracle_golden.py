@@ -114,6 +114,22 @@ def _check(tag, out, c, keys, exact=True):
             assert np.allclose(got, want, rtol=1e-6, atol=0), (tag, key, got, want)
 
 
+def _check_inertia(tag, out, c):
+    """The eight total / dark matter inertia tensors (inertia_tensors.py:19-132): same particles, same
+    np.linalg.eigh, so the iterations agree to rounding."""
+    n = 0
+    for key in ho.INERTIA_KEYS:
+        want = c[f"{tag}/{key}"]
+        got = out.get(key)
+        if np.all(np.isnan(want)):
+            assert got is None or np.all(np.asarray(got) == 0), (tag, key, got)
+            continue
+        got = np.asarray(got, dtype=np.float64)
+        assert np.allclose(got, want, rtol=1e-11, atol=1e-13 * np.abs(want).max()), (tag, key, got, want)
+        n += 1
+    return n
+
+
 ROT_KEYS = ("kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar")
 
 
@@ -137,7 +153,7 @@ def test_particle_data_classes_match_reference():
     reference, property by property, on random single- and multi-type halos."""
     g = np.load(os.path.join(GOLD, "particle_data_classes.npz"))
     u0 = _units(g)
-    n_so = n_ap = n_nu = n_flow = n_short = n_rot = 0
+    n_so = n_ap = n_nu = n_flow = n_short = n_rot = n_inertia = 0
     for i in range(int(g["ncases"])):
         c, data = _case(g, i)
         u = dataclasses.replace(u0, nu_density=float(c["nu_density"]))
@@ -182,6 +198,7 @@ def test_particle_data_classes_match_reference():
             _check(tag, out, c, ["com_gas", "com_star", "vcom_gas", "vcom_star", "Lgas", "Lstar", "Lbaryons"])
             _check(tag, out, c, ["Nnu", "Mnu", "MnuNS"])
             n_rot += _check_rotation(tag, out, c, ("DtoTgas", "DtoTstar"))
+            n_inertia += _check_inertia(tag, out, c)
             n_nu += int(6 in data and out.get("Nnu", 0) > 0)
             # concentration: the reference rounds to float32 (SO_properties.py:2735)
             _check(tag, out, c, ["concentration_unsoft", "concentration_soft"], exact=False)
@@ -218,6 +235,7 @@ def test_particle_data_classes_match_reference():
             else:
                 assert np.allclose(got.reshape(want.shape), want, rtol=RTOL, atol=0), (i, key, got, want)
         n_rot += _check_rotation("SH", out, c)
+        n_inertia += _check_inertia("SH", out, c)
         for vk in ("veldisp_matrix_dm", "veldisp_matrix_gas", "veldisp_matrix_star"):
             want = c[f"SH/{vk}"]
             if not np.all(np.isnan(want)):
@@ -232,4 +250,4 @@ def test_particle_data_classes_match_reference():
                                                 "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
                                                 "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
                                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
-    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20 and n_rot > 150
+    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20 and n_rot > 150 and n_inertia > 300

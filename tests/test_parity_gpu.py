@@ -56,6 +56,8 @@ def compare_halo(o, hr, sc, rtol=1e-10):
         M, vscale = _scales(o, group)
         R = sc.boxsize  # generous length scale for com offsets
         scale = _abs_scale(key, M, vscale)
+        if "InertiaTensor" in key:   # off-diagonal terms are differences: compare on the scale of the tensor
+            scale = float(np.abs(want).max())
         helpers.assert_close(okey, got, want, rtol=rtol, scale=scale, atol_factor=1e-12)
     return nchecked
 
@@ -283,6 +285,8 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
             else:
                 M, vscale = _scales(o, group)
                 scale = _abs_scale(key, M, vscale)
+                if "InertiaTensor" in key:
+                    scale = float(np.abs(want).max())
                 helpers.assert_close(okey, got, want, rtol=1e-10, scale=scale, atol_factor=1e-12)
     assert nchecked > 5000
     ngas = sum(int(helpers.engine_value(r, "BoundSubhalo", "Ngas")[0]) for r in results)
@@ -688,7 +692,7 @@ def test_full_size_invariants_c3(built_library):
     _lap("runs compared")
     ok = st == 0
     assert ok.sum() > 0.99 * H and np.all(st >= 0)
-    coloff = np.concatenate([[0], np.cumsum([layout.NCOLS[hp.kind] for hp in props])])
+    coloff = np.concatenate([[0], np.cumsum([layout.desc_columns(hp.calc_desc(props, i)) for i, hp in enumerate(props)])])
     blk = {hp.name: t[ok][:, coloff[i] : coloff[i + 1]] for i, hp in enumerate(props)}
     sub = blk["bound_subhalo"]
     S, SO, AP = layout.SUBHALO_COLS, layout.SO_COLS, layout.APERTURE_COLS
@@ -755,7 +759,7 @@ def test_full_size_invariants_c5_hydro(built_library):
     assert np.array_equal(st, tables[1]["status"]) and np.array_equal(t, tables[1]["table"])
     ok = st == 0
     assert ok.sum() > 0.99 * H and np.all(st >= 0)
-    coloff = np.concatenate([[0], np.cumsum([layout.NCOLS[hp.kind] for hp in props])])
+    coloff = np.concatenate([[0], np.cumsum([layout.desc_columns(hp.calc_desc(props, i)) for i, hp in enumerate(props)])])
     S, AP, PJ = layout.SUBHALO_COLS, layout.APERTURE_COLS, layout.PROJECTED_COLS
     sub = t[ok][:, coloff[0] : coloff[1]]
     ntot = sum(sub[:, S[k][0]] for k in ("Ngas", "Ndm", "Nstar", "Nbh"))
@@ -836,7 +840,7 @@ def test_dark_matter_mass_flow_rates(built_library):
     so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "200_mean": {"value": 200.0, "type": "mean"},
                "BN98": {"value": 0.0, "type": "BN98"}, "500_crit": {"value": 500.0, "type": "crit"}}  # fmt: skip
     props = chp.build_halo_prop_list(sc, cf, so_vars, {})
-    assert [p.calc_desc(props, i).flags for i, p in enumerate(props)] == [0, 1, 1, 1, 0]
+    assert [p.calc_desc(props, i).flags & layout.CALC_FLAG_DM_FLOW for i, p in enumerate(props)] == [0, 1, 1, 1, 0]
     engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
     ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, {})
     assert np.array_equal(ha["done"], ha_ref["done"])
@@ -857,7 +861,7 @@ def test_dark_matter_mass_flow_rates(built_library):
     # with the property switched off in the parameter file the SOs alone decide the radius: no halo needs more
     # rounds, some need fewer, and every other column is unchanged
     props_off = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_FlowRateOff())
-    assert all(p.calc_desc(props_off, i).flags == 0 for i, p in enumerate(props_off))
+    assert all(p.calc_desc(props_off, i).flags & layout.CALC_FLAG_DM_FLOW == 0 for i, p in enumerate(props_off))
     engine, ha2, results2, out2 = _run_engine(sc, data_np, halos_np, props_off)
     raw2 = out2[4]
     n_loop2 = raw2["stats"][raw2["status"] == 0][:, 0]
@@ -866,4 +870,61 @@ def test_dark_matter_mass_flow_rates(built_library):
     for j in range(min(len(results), len(results2))):
         assert "SO/200_crit/DarkMatterMassFlowRate" not in results2[j]
         assert np.array_equal(results2[j]["SO/200_crit/SORadius"][4], results[j]["SO/200_crit/SORadius"][4])
+    engine.close()
+
+
+class _InertiaOff:
+    def get_property_filters(self, base_halo_type, names):
+        return {n: (False if "InertiaTensor" in n else "basic") for n in names}
+
+
+def test_inertia_tensors(built_library):
+    """Total / dark matter inertia tensors of the bound subhalo and of SOs (inertia_tensors.py:19-132):
+    iterative ellipsoids that reach into the particles surrounding the SO, fixed-sphere versions, reduced
+    versions; fewer than 20 particles give zeros.  Switched off in the parameter file, their 48 columns per
+    calculation disappear from the table and the other columns keep their values."""
+    sc, data, halos = make_chunk(250000, 120, seed=29)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "50_crit": {"value": 50.0, "type": "crit"},
+               "5xR_200_crit": {"value": 200.0, "type": "crit", "radius_multiple": 5.0}}  # fmt: skip
+    props = chp.build_halo_prop_list(sc, cf, so_vars, {})
+    assert all(p.calc_desc(props, i).flags & layout.CALC_FLAG_INERTIA for i, p in enumerate(props))
+    engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, {})
+    assert np.array_equal(ha["done"], ha_ref["done"])
+    done_rows = np.flatnonzero(ha["done"] == 1)
+    n_full = n_moved = n_zero = 0
+    for j, row in enumerate(done_rows):
+        compare_halo(ref[row], results[j], sc)
+        for grp in ("BoundSubhalo", "SO/200_crit", "SO/50_crit", "SO/5xR_200_crit"):
+            it = helpers.engine_value(results[j], grp, "TotalInertiaTensor")
+            fx = helpers.engine_value(results[j], grp, "TotalInertiaTensorNoniterative")
+            rd = helpers.engine_value(results[j], grp, "TotalInertiaTensorReduced")
+            dm = helpers.engine_value(results[j], grp, "DarkMatterInertiaTensor")
+            assert np.array_equal(dm, it)   # dark-matter-only chunk
+            if not np.any(it):
+                n_zero += 1
+                continue
+            n_full += 1
+            T = np.array([[it[0], it[3], it[4]], [it[3], it[1], it[5]], [it[4], it[5], it[2]]])
+            assert np.all(np.linalg.eigvalsh(T) > 0)
+            if np.any(rd):
+                assert abs(rd[0] + rd[1] + rd[2] - 1.0) < 1e-9   # reduced tensor: unit trace
+            n_moved += int(np.any(it != fx))
+    assert n_full > 200 and n_moved > 150
+    raw = out[4]
+    assert np.array_equal(raw["stats"][raw["status"] == 0][:, 0], [s["n_loop"] for s in stats])
+    ncols_on = engine.row_columns
+    engine.close()
+    props_off = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_InertiaOff())
+    engine, ha2, results2, out2 = _run_engine(sc, data_np, halos_np, props_off)
+    assert engine.row_columns == ncols_on - 48 * len(props_off)
+    for j in range(len(results2)):
+        assert not any("InertiaTensor" in k for k in results2[j])
+        for k, v in results2[j].items():
+            # a radius-multiple SO whose radius is a hair above the search radius is re-evaluated in a larger
+            # sphere when the tensors are on (inertia_tensors.py:110-111): its interpolated mass may differ
+            if not k.startswith("SO/5xR_200_crit/"):
+                assert np.array_equal(v[0], results[j][k][0]), k
     engine.close()
