@@ -123,7 +123,7 @@ enum {
 /* number of fp64 output columns a calculation kind writes (fixed layout, see
  * soap_amd/layout.py which mirrors csrc/layout.h) */
 int32_t soap_engine_calc_columns(int32_t kind);
-/* columns a calculation occupies in THIS run: soap_engine_calc_columns(kind), minus the 48 inertia tensor
+/* columns a calculation occupies in THIS run: soap_engine_calc_columns(kind), minus the 96 inertia tensor
  * columns at the end of the subhalo / SO blocks when SOAP_CALC_FLAG_INERTIA is not set */
 int32_t soap_engine_desc_columns(const soap_calc_desc *desc);
 

@@ -498,7 +498,10 @@ SCHEMA = {
     **{k: (6, np.float32) for k in (
         "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
         "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
-        "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative")},
+        "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+        "GasInertiaTensor", "GasInertiaTensorReduced", "GasInertiaTensorNoniterative",
+        "GasInertiaTensorReducedNoniterative", "StellarInertiaTensor", "StellarInertiaTensorReduced",
+        "StellarInertiaTensorNoniterative", "StellarInertiaTensorReducedNoniterative")},
     # neutrino particles inside an SO (property_table.py: NumberOfNeutrinoParticles, RawNeutrinoMass,
     # NoiseSuppressedNeutrinoMass)
     "Nnu": (1, np.uint32),
@@ -514,6 +517,10 @@ INERTIA_KEYS = (
     "TotalInertiaTensorNoniterative", "TotalInertiaTensorReducedNoniterative",
     "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
     "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+    "GasInertiaTensor", "GasInertiaTensorReduced",
+    "GasInertiaTensorNoniterative", "GasInertiaTensorReducedNoniterative",
+    "StellarInertiaTensor", "StellarInertiaTensorReduced",
+    "StellarInertiaTensorNoniterative", "StellarInertiaTensorReducedNoniterative",
 )
 
 
@@ -577,22 +584,23 @@ def get_weighted_inertia_tensor(particle_weights, particle_positions, sphere_rad
 ENABLE_INERTIA = True
 
 
-def inertia_tensors(out, mass, position, types, R_tot, R_dm, search_radius, has_tot, has_dm, n_inner=None):
+def inertia_tensors(out, mass, position, types, radii, search_radius, has, n_inner=None):
     """
-    The eight dark-matter-only-run tensors of a selection (SO_properties.py:620-672, :915-972;
-    subhalo_properties.py:1075-1125, :1302-1352): total mass and dark matter, iterative and within the fixed
-    sphere (`max_iterations=1`), plain and reduced.  `mass / position / types`: every particle the iterative
+    The sixteen mass-weighted tensors of a selection (SO_properties.py:620-672, :798-857, :915-972, :1160-1218;
+    subhalo_properties.py:1075-1125, :1206-1256, :1302-1352, :1730-1783): total mass, dark matter, gas and
+    stars (`radii` and `has` in that order), iterative and within the fixed sphere (`max_iterations=1`), plain
+    and reduced.  `mass / position / types`: every particle the iterative
     version may use (SO: members first, then the surrounding particles of the search sphere; bound subhalo:
     the bound particles); the fixed-sphere version is handed the same arrays, since particles outside the
-    sphere get weight zero.  R_tot / R_dm: the spheres' radii.  n_inner: the fixed-sphere versions only see the
+    sphere get weight zero.  n_inner: the fixed-sphere versions only see the
     first n_inner particles (SO: the members, SO_properties.py:658-659, :957-958).
     """
     if not ENABLE_INERTIA:
         return
     n_inner = len(mass) if n_inner is None else n_inner
-    dm = types == 1
     inner = np.arange(len(mass)) < n_inner
-    for name, sel, R, ok in (("Total", np.ones(len(mass), dtype=bool), R_tot, has_tot), ("DarkMatter", dm, R_dm, has_dm)):
+    comps = (("Total", np.ones(len(mass), dtype=bool)), ("DarkMatter", types == 1), ("Gas", types == 0), ("Stellar", types == 4))
+    for (name, sel), R, ok in zip(comps, radii, has):
         if not ok:
             continue
         m, x = mass[sel], position[sel]
@@ -794,8 +802,10 @@ class SubhaloProperties:
         out["HalfMassRadiusDM"] = get_half_weight_radius(radius[dm], mass[dm], M_t[1])
         baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize)
         # bound particles inside 10 half-mass radii, no search-radius condition (subhalo_properties.py:1075-1125, :1302-1352)
-        inertia_tensors(out, mass, position, types, 10 * out["HalfMassRadiusTot"], 10 * out["HalfMassRadiusDM"],
-                        None, Mtot != 0, M_t[1] != 0)
+        inertia_tensors(out, mass, position, types,
+                        (10 * out["HalfMassRadiusTot"], 10 * out["HalfMassRadiusDM"],
+                         10 * out["HalfMassRadiusGas"], 10 * out["HalfMassRadiusStar"]),
+                        None, (Mtot != 0, M_t[1] != 0, M_t[0] != 0, M_t[4] != 0))
 
         for key in self.property_list:
             _store(halo_result, g, key, out.get(key))
@@ -1044,8 +1054,8 @@ class SOProperties:
                 R1 += missed_mass * SO_r
                 R1 /= SO_r * SO_mass
                 out[key] = concentration_from_R1(R1)
-        inertia_tensors(out, it_mass, it_pos, it_types, SO_r, SO_r, search_radius, Mtotpart != 0, M_t[1] != 0,
-                        n_inner=int(sel.sum()))
+        inertia_tensors(out, it_mass, it_pos, it_types, (SO_r,) * 4, search_radius,
+                        (Mtotpart != 0, M_t[1] != 0, M_t[0] != 0, M_t[4] != 0), n_inner=int(sel.sum()))
         if self.virial_definition and N[1] != 0:
             # DarkMatterMassFlowRate (SO_properties.py:2919-2932): all loaded dark matter, not only r < R_SO
             out["DarkMatterMassFlowRate"] = mass_flow_rate(

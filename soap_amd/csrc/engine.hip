@@ -813,8 +813,8 @@ const char *soap_engine_last_error(void) { return g_err.c_str(); }
 int32_t soap_engine_desc_columns(const soap_calc_desc *desc) {
     if (!desc) return -1;
     int32_t nc = soap_engine_calc_columns(desc->kind);
-    // the inertia tensors are the last 48 columns of the subhalo and SO blocks: only there when wanted
-    if (nc > 0 && desc->kind <= SOAP_CALC_SO_MULTIPLE && !(desc->flags & SOAP_CALC_FLAG_INERTIA)) nc -= 48;
+    // the inertia tensors are the last columns of the subhalo and SO blocks: only there when wanted
+    if (nc > 0 && desc->kind <= SOAP_CALC_SO_MULTIPLE && !(desc->flags & SOAP_CALC_FLAG_INERTIA)) nc -= INERTIA_NCOLS;
     return nc;
 }
 

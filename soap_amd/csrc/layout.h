@@ -18,9 +18,9 @@ enum {
     // ordered rotation: kappa_corot of gas / stars / baryons, disc-to-total fractions of gas / stars
     SH_kappa = 58, SH_DtoT = 61,
     // inertia tensors (xx yy zz xy xz yz each): total {iterative, reduced, fixed sphere, reduced fixed sphere},
-    // then the same four for the dark matter
+    // then the same four for the dark matter, the gas and the stars
     SH_inertia = 63,
-    SH_NCOLS = 111
+    SH_NCOLS = 159
 };
 // ---- SOAP_CALC_SO_* -------------------------------------------------------------
 enum {
@@ -38,8 +38,10 @@ enum {
     SOC_Nnu = 47, SOC_Mnu, SOC_MnuNS,   // neutrino particles inside the sphere
     SOC_flow = 50,                      // dark matter mass flow rate: inflow at 0.1 / 0.3 / 1 R_SO, outflow at the same
     SOC_DtoT = 56,                      // disc-to-total fractions of gas / stars
-    SOC_inertia = 58,                   // eight inertia tensors, as in the bound subhalo block
-    SOC_NCOLS = 106
+    SOC_inertia = 58,                   // sixteen inertia tensors, as in the bound subhalo block
+    SOC_NCOLS = 154
+};
+enum { INERTIA_NCOLS = 96
 };
 // ---- SOAP_CALC_APERTURE_* ---------------------------------------------------------
 enum {

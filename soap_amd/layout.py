@@ -18,12 +18,16 @@ CALC_FLAG_DM_FLOW = 1
 CALC_FLAG_ROTATION = 2
 CALC_FLAG_INERTIA = 4
 
-# total / dark matter inertia tensors, in column order
+# total / dark matter / gas / stellar inertia tensors, in column order
 INERTIA_KEYS = (
     "TotalInertiaTensor", "TotalInertiaTensorReduced",
     "TotalInertiaTensorNoniterative", "TotalInertiaTensorReducedNoniterative",
     "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
     "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+    "GasInertiaTensor", "GasInertiaTensorReduced",
+    "GasInertiaTensorNoniterative", "GasInertiaTensorReducedNoniterative",
+    "StellarInertiaTensor", "StellarInertiaTensorReduced",
+    "StellarInertiaTensorNoniterative", "StellarInertiaTensorReducedNoniterative",
 )
 
 SUBHALO_COLS = {
@@ -74,10 +78,10 @@ PROJECTED_COLS = {
 PROJECTED_NCOLS = 25
 
 NCOLS = {
-    CALC_SUBHALO: 111,
-    CALC_SO_DENSITY: 106,
-    CALC_SO_PHYSICAL: 106,
-    CALC_SO_MULTIPLE: 106,
+    CALC_SUBHALO: 159,
+    CALC_SO_DENSITY: 154,
+    CALC_SO_PHYSICAL: 154,
+    CALC_SO_MULTIPLE: 154,
     CALC_APERTURE_INCL: 62,
     CALC_APERTURE_EXCL: 62,
     CALC_PROJECTED: 3 * PROJECTED_NCOLS,
@@ -98,7 +102,7 @@ def columns_of(kind):
 
 def desc_columns(desc) -> int:
     """Columns a calculation occupies in one run (mirror of soap_engine_desc_columns): the full width of its
-    kind, minus the 48 inertia tensor columns that end the subhalo / SO blocks when they are not wanted."""
+    kind, minus the 96 inertia tensor columns that end the subhalo / SO blocks when they are not wanted."""
     nc = NCOLS[desc.kind]
     if desc.kind <= CALC_SO_MULTIPLE and not (desc.flags & CALC_FLAG_INERTIA):
         nc -= 6 * len(INERTIA_KEYS)

@@ -90,6 +90,14 @@ full_property_list = {
     "DarkMatterInertiaTensorReduced": Property("DarkMatterInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "DarkMatterInertiaTensorNoniterative": Property("DarkMatterInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "DarkMatterInertiaTensorReducedNoniterative": Property("DarkMatterInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, True, 0, "3D inertia tensor of the dark matter distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "GasInertiaTensor": Property("GasInertiaTensor", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the gas mass distribution relative to the halo centre (computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "GasInertiaTensorReduced": Property("GasInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the gas mass distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "GasInertiaTensorNoniterative": Property("GasInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the gas mass distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "GasInertiaTensorReducedNoniterative": Property("GasInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the gas mass distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "StellarInertiaTensor": Property("StellarInertiaTensor", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "StellarInertiaTensorReduced": Property("StellarInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "StellarInertiaTensorNoniterative": Property("StellarInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "StellarInertiaTensorReducedNoniterative": Property("StellarInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "kappa_corot_gas": Property("KappaCorotGas", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the gas in ordered co-rotation (Correa et al. 2017)."),
     "kappa_corot_star": Property("KappaCorotStars", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the stars in ordered co-rotation."),
     "kappa_corot_baryons": Property("KappaCorotBaryons", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of gas and stars in ordered co-rotation."),

@@ -265,7 +265,10 @@ def main():
                          "Nnu", "Mnu", "MnuNS", "DtoTgas", "DtoTstar",
                          "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
                          "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
-                         "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative"]:
+                         "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+                         "GasInertiaTensor", "GasInertiaTensorReduced", "GasInertiaTensorNoniterative",
+                         "GasInertiaTensorReducedNoniterative", "StellarInertiaTensor", "StellarInertiaTensorReduced",
+                         "StellarInertiaTensorNoniterative", "StellarInertiaTensorReducedNoniterative"]:
                 val = getattr(pp, name)
                 case[f"{tag}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
             # dark matter mass flow rates through the three shells (SO_properties.py:2816-2932); the outer shell
@@ -309,7 +312,10 @@ def main():
                      "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
                      "TotalInertiaTensor", "TotalInertiaTensorReduced", "TotalInertiaTensorNoniterative",
                      "TotalInertiaTensorReducedNoniterative", "DarkMatterInertiaTensor", "DarkMatterInertiaTensorReduced",
-                     "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative"]:
+                     "DarkMatterInertiaTensorNoniterative", "DarkMatterInertiaTensorReducedNoniterative",
+                         "GasInertiaTensor", "GasInertiaTensorReduced", "GasInertiaTensorNoniterative",
+                         "GasInertiaTensorReducedNoniterative", "StellarInertiaTensor", "StellarInertiaTensorReduced",
+                         "StellarInertiaTensorNoniterative", "StellarInertiaTensorReducedNoniterative"]:
             val = getattr(pp, name)
             case[f"SH/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         # projected

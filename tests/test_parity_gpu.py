@@ -306,6 +306,11 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
                 assert -1.0 - 1e-12 <= d <= 1.0 + 1e-12
                 nrot += int(-1.0 < d < 1.0 and d != 0.0)
     assert nrot > 500
+    # gas and stellar inertia tensors exist where the component has at least 20 particles
+    ntens = sum(int(np.any(helpers.engine_value(r, grp, key)))
+                for r in results for grp in ("BoundSubhalo", "SO/200_crit")
+                for key in ("GasInertiaTensor", "StellarInertiaTensorReduced", "GasInertiaTensorNoniterative"))
+    assert ntens > 100
     engine.close()
 
 
@@ -881,7 +886,7 @@ class _InertiaOff:
 def test_inertia_tensors(built_library):
     """Total / dark matter inertia tensors of the bound subhalo and of SOs (inertia_tensors.py:19-132):
     iterative ellipsoids that reach into the particles surrounding the SO, fixed-sphere versions, reduced
-    versions; fewer than 20 particles give zeros.  Switched off in the parameter file, their 48 columns per
+    versions; fewer than 20 particles give zeros.  Switched off in the parameter file, their 96 columns per
     calculation disappear from the table and the other columns keep their values."""
     sc, data, halos = make_chunk(250000, 120, seed=29)
     data_np, halos_np = to_numpy(data, halos)
@@ -919,7 +924,7 @@ def test_inertia_tensors(built_library):
     engine.close()
     props_off = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_InertiaOff())
     engine, ha2, results2, out2 = _run_engine(sc, data_np, halos_np, props_off)
-    assert engine.row_columns == ncols_on - 48 * len(props_off)
+    assert engine.row_columns == ncols_on - 96 * len(props_off)
     for j in range(len(results2)):
         assert not any("InertiaTensor" in k for k in results2[j])
         for k, v in results2[j].items():
