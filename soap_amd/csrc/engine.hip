@@ -1191,7 +1191,12 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
 
     // three classes of halos by estimated sphere content: one wavefront, 256 threads, 1024 threads per
     // halo.  A halo whose search sphere outgrows its class' slab is retried in the next class.
-    long long nb_small = 8192, nb_medium = 131072;
+    // (thresholds from scripts/sweep.sh on C3: 8192 / 131072 gave 29.4 ms of halo kernels, 16384 / 262144 27.3 ms;
+    // the largest halo alone keeps one 1024-thread group busy for ~22 ms, so the giants class should hold little else)
+    // Chunks with gas and stars do about twice the work per particle (typed passes, projected apertures): there the
+    // 256-thread class keeps the lower limit (C5: 131072 gives 29.7 ms/step, 262144 37.9 ms/step).
+    long long nb_small = 16384, nb_medium = 262144;
+    if (h->t[0].n > 0 || h->t[2].n > 0) nb_medium = 131072;
     { const char *e = getenv("SOAP_ENGINE_NB_SMALL"); if (e) nb_small = atoll(e); }
     { const char *e = getenv("SOAP_ENGINE_NB_MEDIUM"); if (e) nb_medium = atoll(e); }
     long long caps[3] = {1ll << 15, 1ll << 18, 1ll << 20};
