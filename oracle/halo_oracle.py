@@ -493,6 +493,10 @@ SCHEMA = {
     "kappa_corot_baryons": (1, np.float32),
     "DtoTgas": (1, np.float32),
     "DtoTstar": (1, np.float32),
+    # mass fraction of the bound stars born in another subhalo: dark-matter-only runs carry the (zero) column
+    # (aperture_properties.py:764-780, subhalo_properties.py; `Nstar == 0` gives None); with stars it needs
+    # PartType4/BirthHaloCatalogueIndex, which is outside this path
+    "ExSituFraction": (1, np.float32),
     # inertia tensors of the total and the dark matter mass (property_table.py:2724-2790 and the DarkMatter rows):
     # xx yy zz xy xz yz
     **{k: (6, np.float32) for k in (
@@ -809,6 +813,8 @@ class SubhaloProperties:
 
         for key in self.property_list:
             _store(halo_result, g, key, out.get(key))
+        if self.dmo:
+            _store(halo_result, g, "ExSituFraction", None)
         halo_result["_counts"] = counts
 
 
@@ -1194,6 +1200,8 @@ class ApertureProperties:
             if search_radius < aperture_radius:
                 raise SearchRadiusTooSmallError("Search radius is smaller than aperture")
             out = self._calculate(input_halo, aperture_radius, data)
+        if self.dmo:
+            _store(halo_result, g, "ExSituFraction", None)
         for key in self.property_list:
             if copied is not None:
                 pv = halo_result[f"{copied}/{key}"]

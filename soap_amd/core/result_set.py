@@ -50,8 +50,11 @@ class ResultSet:
             for proj, base in _projections(hp):
                 for key in hp.enabled_properties():
                     prop = full_property_list[key]
-                    c0, nc = cols[key]
-                    raw = block[:, base + c0 : base + c0 + nc]
+                    if key in layout.VIRTUAL_ZERO_KEYS:
+                        raw = np.zeros((n, prop.shape))
+                    else:
+                        c0, nc = cols[key]
+                        raw = block[:, base + c0 : base + c0 + nc]
                     filt = hp.property_filters.get(prop.name, "basic")
                     if ci > 0 and filt != "basic" and filt in do_calc:   # the subhalo itself is never filtered
                         raw = np.where(do_calc[filt][:, None], raw, 0.0)

@@ -100,6 +100,12 @@ def columns_of(kind):
     raise KeyError(kind)
 
 
+# properties that a dark-matter-only run carries as a column of zeros without any engine column behind them
+# (ExSituFraction: `Nstar == 0` gives None, aperture_properties.py:764-769); with stars they would need
+# datasets outside this path, so they are only emitted in DMO runs
+VIRTUAL_ZERO_KEYS = ("ExSituFraction",)
+
+
 def desc_columns(desc) -> int:
     """Columns a calculation occupies in one run (mirror of soap_engine_desc_columns): the full width of its
     kind, minus the 96 inertia tensor columns that end the subhalo / SO blocks when they are not wanted."""

@@ -88,6 +88,8 @@ class HaloProperty:
                 continue
             if dmo and not prop.dmo_property:
                 continue
+            if key in layout.VIRTUAL_ZERO_KEYS and not dmo:
+                continue
             out.append(key)
         return out
 
@@ -131,8 +133,11 @@ class HaloProperty:
         cols = layout.columns_of(self.kind)
         for key in self.enabled_properties():
             prop = full_property_list[key]
-            c0, nc = cols[key]
-            raw = block[c0 : c0 + nc].copy()
+            if key in layout.VIRTUAL_ZERO_KEYS:
+                raw = np.zeros(prop.shape, dtype=np.float64)
+            else:
+                c0, nc = cols[key]
+                raw = block[c0 : c0 + nc].copy()
             filt = self.property_filters.get(prop.name, "basic")
             if do_calculation is not None and not do_calculation.get(filt, True):
                 raw[:] = 0.0

@@ -21,7 +21,7 @@ class SubhaloProperties(HaloProperty):
         "HalfMassRadiusTot", "HalfMassRadiusDM", "veldisp_matrix_dm", "EncloseRadius",
         "com_star", "Lgas", "Lstar", "Lbaryons", "veldisp_matrix_gas", "veldisp_matrix_star",
         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
-        "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
+        "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar", "ExSituFraction",
         *layout.INERTIA_KEYS,
     ]  # fmt: skip
 

@@ -98,6 +98,7 @@ full_property_list = {
     "StellarInertiaTensorReduced": Property("StellarInertiaTensorReduced", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "StellarInertiaTensorNoniterative": Property("StellarInertiaTensorNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "StellarInertiaTensorReducedNoniterative": Property("StellarInertiaTensorReducedNoniterative", 6, np.float32, "snap_length**2", False, 2, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "ExSituFraction": Property("ExSituFraction", 1, np.float32, "dimensionless", True, 0, True, 0, "Mass fraction of bound stars that formed in a different subhalo (zero without stars)."),
     "kappa_corot_gas": Property("KappaCorotGas", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the gas in ordered co-rotation (Correa et al. 2017)."),
     "kappa_corot_star": Property("KappaCorotStars", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of the stars in ordered co-rotation."),
     "kappa_corot_baryons": Property("KappaCorotBaryons", 1, np.float32, "dimensionless", True, None, False, 0, "Kinetic energy fraction of gas and stars in ordered co-rotation."),
