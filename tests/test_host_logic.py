@@ -148,3 +148,22 @@ def test_result_set_columns_from_a_table():
     assert len(cols) == want
     # the first column of the table is BoundSubhalo/TotalMass, stored as float32
     assert np.array_equal(cols["BoundSubhalo/TotalMass"], table[:, 0].astype(np.float32))
+
+
+def test_property_table_rows_are_the_references():
+    """Every row of soap_amd/property_table.py against the reference's table (fixture written by
+    tests/golden/make_property_rows.py): output name, shape, dtype, unit, DMO flag, physical / comoving output and
+    the a-scale exponent are what a SOAP catalogue carries."""
+    import json
+    import os
+
+    from soap_amd.property_table import full_property_list
+
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "property_rows.json")))
+    assert sorted(rows) == sorted(full_property_list)
+    for key, prop in full_property_list.items():
+        r = rows[key]
+        got = (prop.name, prop.shape, np.dtype(prop.dtype).name, prop.unit.replace(" ", ""), prop.dmo_property,
+               prop.output_physical, prop.a_scale_exponent)
+        want = (r["name"], r["shape"], r["dtype"], r["unit"], r["dmo_property"], r["output_physical"], r["a_scale_exponent"])
+        assert got == want, (key, got, want)
