@@ -124,7 +124,8 @@ enum {
  * soap_amd/layout.py which mirrors csrc/layout.h) */
 int32_t soap_engine_calc_columns(int32_t kind);
 /* columns a calculation occupies in THIS run: soap_engine_calc_columns(kind), minus the 96 inertia tensor
- * columns at the end of the subhalo / SO blocks when SOAP_CALC_FLAG_INERTIA is not set */
+ * columns at the end of the subhalo / SO blocks when SOAP_CALC_FLAG_INERTIA is not set; plus the 108 columns of
+ * the 2D tensors after the three projection blocks of a projected aperture when it is set */
 int32_t soap_engine_desc_columns(const soap_calc_desc *desc);
 
 int32_t soap_engine_abi_version(void);

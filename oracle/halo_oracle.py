@@ -493,6 +493,9 @@ SCHEMA = {
     "kappa_corot_baryons": (1, np.float32),
     "DtoTgas": (1, np.float32),
     "DtoTstar": (1, np.float32),
+    # 2D inertia tensors of projected apertures (property_table.py:2150-2280): (1,1), (2,2), (1,2)
+    **{f"Projected{c}InertiaTensor{s_}": (3, np.float32) for c in ("Total", "Gas", "Stellar")
+       for s_ in ("", "Reduced", "Noniterative", "ReducedNoniterative")},
     # mass fraction of the bound stars born in another subhalo: dark-matter-only runs carry the (zero) column
     # (aperture_properties.py:764-780, subhalo_properties.py; `Nstar == 0` gives None); with stars it needs
     # PartType4/BirthHaloCatalogueIndex, which is outside this path
@@ -586,6 +589,70 @@ def get_weighted_inertia_tensor(particle_weights, particle_positions, sphere_rad
 # the parameter file can switch properties off (parameter_file.py:85-154); the only switch this restatement
 # needs is the one for the inertia tensors, whose iterations dominate the run time when they are on
 ENABLE_INERTIA = True
+
+
+PROJECTED_INERTIA_KEYS = tuple(
+    f"Projected{comp}InertiaTensor{suffix}"
+    for comp in ("Total", "Gas", "Stellar")
+    for suffix in ("", "Reduced", "Noniterative", "ReducedNoniterative")
+)
+
+
+def get_weighted_projected_inertia_tensor(particle_weights, particle_positions, axis, radius, reduced=False,
+                                          max_iterations=20, min_particles=20):  # fmt: skip
+    """
+    property_calculation/inertia_tensors.py:226-343: the same iteration in projection along `axis` (0: (y, z),
+    1: (z, x), 2: (x, y)), with an ellipse of the area of the circle of `radius`; eigenvalues are used as they
+    come (no absolute value), there is no search-radius condition.  Returns (I_11, I_22, I_12) or None.
+    """
+    if particle_weights.shape[0] < min_particles:
+        return None
+    projected_position = np.zeros((particle_positions.shape[0], 2), dtype=particle_positions.dtype)
+    if axis == 0:
+        projected_position[:, 0] = particle_positions[:, 1]
+        projected_position[:, 1] = particle_positions[:, 2]
+    elif axis == 1:
+        projected_position[:, 0] = particle_positions[:, 2]
+        projected_position[:, 1] = particle_positions[:, 0]
+    elif axis == 2:
+        projected_position[:, 0] = particle_positions[:, 0]
+        projected_position[:, 1] = particle_positions[:, 1]
+    else:
+        raise AttributeError(f"Invalid axis: {axis}!")
+    if reduced:
+        norm = np.linalg.norm(projected_position, axis=1) ** 2
+        mask = np.logical_not(np.isclose(norm, 0))
+        norm = norm[mask]
+        particle_weights = particle_weights[mask]
+        projected_position = projected_position[mask]
+    tol = 0.0001
+    q = 1000
+    R = radius
+    eig_val = [1, 1]
+    eig_vec = np.array([[1, 0], [0, 1]])
+    tensor = None
+    for i_iter in range(max_iterations):
+        old_q = q
+        with np.errstate(all="ignore"):
+            q = np.sqrt(eig_val[0] / eig_val[1])
+            if abs((old_q - q) / q) < tol:
+                break
+            ax = R * np.array([1 * np.sqrt(q), 1 / np.sqrt(q)])
+            p = np.dot(projected_position, eig_vec) / ax
+            r = np.linalg.norm(p, axis=1)
+            if (i_iter == 0) and (np.sum(r <= 1) < min_particles):
+                return None
+            weight = particle_weights / np.sum(particle_weights[r <= 1])
+            weight[r > 1] = 0
+            tensor = weight[:, None, None] * projected_position[:, :, None] * projected_position[:, None, :]
+            if reduced:
+                tensor /= norm[:, None, None]
+            tensor = tensor.sum(axis=0)
+            eig_val, eig_vec = np.linalg.eigh(tensor)
+        if q == 0:
+            tensor.fill(0)
+            break
+    return np.concatenate([np.diag(tensor), [tensor[(0, 1)]]])
 
 
 def inertia_tensors(out, mass, position, types, radii, search_radius, has, n_inner=None):
@@ -1276,7 +1343,8 @@ class ProjectedApertureProperties:
     property_list = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar",
                      "Nbh", "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm",
                      "com_star", "proj_veldisp_gas", "proj_veldisp_star",
-                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]  # fmt: skip
+                     "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+                     *PROJECTED_INERTIA_KEYS]  # fmt: skip
 
     def __init__(self, units: Units, radius_kpc: float, all_radii_kpc=None,
                  halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
@@ -1388,6 +1456,18 @@ class ProjectedApertureProperties:
             out["HalfMassRadiusGas"] = get_half_weight_radius(r[gas], m[gas], M_t[0])
             out["HalfMassRadiusStar"] = get_half_weight_radius(r[star], m[star], M_t[4])
             out["HalfMassRadiusBaryon"] = get_half_weight_radius(r[bar], m[bar], m[bar].sum())
+            # projected inertia tensors (projected_aperture_properties.py:788-850, :876-940, :1005-1068): iterative
+            # over ALL bound particles of the component, fixed circle over those inside the aperture
+            if ENABLE_INERTIA:
+                for comp, all_sel, in_sel, Mk in (("Total", np.ones(len(mass), dtype=bool), np.ones(len(m), dtype=bool), Mtot),
+                                                  ("Gas", types == 0, gas, M_t[0]), ("Stellar", types == 4, star, M_t[4])):
+                    if Mk == 0:
+                        continue
+                    for suffix, kw in (("", {}), ("Reduced", {"reduced": True})):
+                        out[f"Projected{comp}InertiaTensor{suffix}"] = get_weighted_projected_inertia_tensor(
+                            mass[all_sel], position[all_sel], iproj, aperture_radius, **kw)
+                        out[f"Projected{comp}InertiaTensor{suffix}Noniterative"] = get_weighted_projected_inertia_tensor(
+                            m[in_sel], x[in_sel], iproj, aperture_radius, max_iterations=1, **kw)
             outs[proj] = out
         return outs
 

@@ -47,11 +47,14 @@ class ResultSet:
         for ci, hp in enumerate(self.props):
             block = table[:, self.coloff[ci] : self.coloff[ci + 1]]
             cols = layout.columns_of(hp.kind)
-            for proj, base in _projections(hp):
+            for iproj, (proj, base) in enumerate(_projections(hp)):
                 for key in hp.enabled_properties():
                     prop = full_property_list[key]
                     if key in layout.VIRTUAL_ZERO_KEYS:
                         raw = np.zeros((n, prop.shape))
+                    elif hp.kind == layout.CALC_PROJECTED:
+                        c0, nc = layout.projected_columns(key, iproj)
+                        raw = block[:, c0 : c0 + nc]
                     else:
                         c0, nc = cols[key]
                         raw = block[:, base + c0 : base + c0 + nc]

@@ -815,6 +815,8 @@ int32_t soap_engine_desc_columns(const soap_calc_desc *desc) {
     int32_t nc = soap_engine_calc_columns(desc->kind);
     // the inertia tensors are the last columns of the subhalo and SO blocks: only there when wanted
     if (nc > 0 && desc->kind <= SOAP_CALC_SO_MULTIPLE && !(desc->flags & SOAP_CALC_FLAG_INERTIA)) nc -= INERTIA_NCOLS;
+    // projected apertures: the 2D tensors follow the three projection blocks
+    if (desc->kind == SOAP_CALC_PROJECTED && (desc->flags & SOAP_CALC_FLAG_INERTIA)) nc += PJ_INERTIA_NCOLS;
     return nc;
 }
 

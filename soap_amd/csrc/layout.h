@@ -66,3 +66,6 @@ enum {
     PJ_HMR_gas = 22, PJ_HMR_star, PJ_HMR_baryon,
     PJ_NCOLS = 25
 };
+// 2D inertia tensors of a projected aperture, only with SOAP_CALC_FLAG_INERTIA: after the three projection blocks,
+// per projection 36 columns = {total, gas, stars} x {iterative, reduced, fixed circle, reduced fixed circle} x (11, 22, 12)
+enum { PJ_INERTIA_PER_AXIS = 36, PJ_INERTIA_NCOLS = 108 };

@@ -106,10 +106,29 @@ def columns_of(kind):
 VIRTUAL_ZERO_KEYS = ("ExSituFraction",)
 
 
+# 2D inertia tensors of projected apertures: after the three projection blocks, 36 columns per projection
+PROJECTED_INERTIA_KEYS = tuple(
+    f"Projected{comp}InertiaTensor{suffix}"
+    for comp in ("Total", "Gas", "Stellar")
+    for suffix in ("", "Reduced", "Noniterative", "ReducedNoniterative")
+)
+PROJECTED_INERTIA_PER_AXIS = 3 * len(PROJECTED_INERTIA_KEYS)
+
+
+def projected_columns(key, iproj):
+    """(first column, number of columns) of `key` for projection `iproj` inside a projected aperture's block."""
+    if key in PROJECTED_INERTIA_KEYS:
+        return 3 * PROJECTED_NCOLS + iproj * PROJECTED_INERTIA_PER_AXIS + 3 * PROJECTED_INERTIA_KEYS.index(key), 3
+    c0, nc = PROJECTED_COLS[key]
+    return iproj * PROJECTED_NCOLS + c0, nc
+
+
 def desc_columns(desc) -> int:
     """Columns a calculation occupies in one run (mirror of soap_engine_desc_columns): the full width of its
     kind, minus the 96 inertia tensor columns that end the subhalo / SO blocks when they are not wanted."""
     nc = NCOLS[desc.kind]
     if desc.kind <= CALC_SO_MULTIPLE and not (desc.flags & CALC_FLAG_INERTIA):
         nc -= 6 * len(INERTIA_KEYS)
+    if desc.kind == CALC_PROJECTED and (desc.flags & CALC_FLAG_INERTIA):
+        nc += 3 * PROJECTED_INERTIA_PER_AXIS
     return nc

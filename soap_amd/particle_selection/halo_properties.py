@@ -74,7 +74,7 @@ class HaloProperty:
         if any(k in _ROTATION_KEYS for k in self.enabled_properties()):
             d.flags |= layout.CALC_FLAG_ROTATION
         # inertia tensors: iterative passes over the particles of the search sphere (inertia_tensors.py:19-132)
-        if any(k in layout.INERTIA_KEYS for k in self.enabled_properties()):
+        if any(k in layout.INERTIA_KEYS or k in layout.PROJECTED_INERTIA_KEYS for k in self.enabled_properties()):
             d.flags |= layout.CALC_FLAG_INERTIA
         return d
 

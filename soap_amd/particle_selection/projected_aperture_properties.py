@@ -22,7 +22,8 @@ class ProjectedApertureProperties(HaloProperty):
     property_names = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
                       "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm",
                       "com_star", "proj_veldisp_gas", "proj_veldisp_star",
-                      "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]  # fmt: skip
+                      "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+                      *layout.PROJECTED_INERTIA_KEYS]  # fmt: skip
 
     def __init__(self, cellgrid, parameters, aperture_physical_radius_kpc, aperture_property,
                  category_filter, halo_filter, all_radii_kpc):  # fmt: skip
@@ -58,13 +59,11 @@ class ProjectedApertureProperties(HaloProperty):
         return d
 
     def unpack(self, block: np.ndarray, halo_result: Dict, do_calculation=None):
-        cols = layout.PROJECTED_COLS
         for iproj, projname in enumerate(("projx", "projy", "projz")):
-            sub = block[iproj * layout.PROJECTED_NCOLS : (iproj + 1) * layout.PROJECTED_NCOLS]
             for key in self.enabled_properties():
                 prop = full_property_list[key]
-                c0, nc = cols[key]
-                raw = sub[c0 : c0 + nc].copy()
+                c0, nc = layout.projected_columns(key, iproj)
+                raw = block[c0 : c0 + nc].copy()
                 filt = self.property_filters.get(prop.name, "basic")
                 if do_calculation is not None and not do_calculation.get(filt, True):
                     raw[:] = 0.0

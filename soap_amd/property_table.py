@@ -98,6 +98,18 @@ full_property_list = {
     "StellarInertiaTensorReduced": Property("StellarInertiaTensorReduced", 6, np.float32, "dimensionless", True, 0, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, computed iteratively): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "StellarInertiaTensorNoniterative": Property("StellarInertiaTensorNoniterative", 6, np.float32, "snap_length**2", True, 2, False, 2, "3D inertia tensor of the stellar mass distribution relative to the halo centre (from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
     "StellarInertiaTensorReducedNoniterative": Property("StellarInertiaTensorReducedNoniterative", 6, np.float32, "dimensionless", True, 0, False, 0, "3D inertia tensor of the stellar mass distribution relative to the halo centre (reduced, from the particles inside the initial sphere): (1,1), (2,2), (3,3), (1,2), (1,3), (2,3). Only calculated with at least 20 particles."),
+    "ProjectedTotalInertiaTensor": Property("ProjectedTotalInertiaTensor", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the total mass distribution in projection (computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedTotalInertiaTensorReduced": Property("ProjectedTotalInertiaTensorReduced", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the total mass distribution in projection (reduced, computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedTotalInertiaTensorNoniterative": Property("ProjectedTotalInertiaTensorNoniterative", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the total mass distribution in projection (from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
+    "ProjectedTotalInertiaTensorReducedNoniterative": Property("ProjectedTotalInertiaTensorReducedNoniterative", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the total mass distribution in projection (reduced, from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
+    "ProjectedGasInertiaTensor": Property("ProjectedGasInertiaTensor", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the gas mass distribution in projection (computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedGasInertiaTensorReduced": Property("ProjectedGasInertiaTensorReduced", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the gas mass distribution in projection (reduced, computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedGasInertiaTensorNoniterative": Property("ProjectedGasInertiaTensorNoniterative", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the gas mass distribution in projection (from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
+    "ProjectedGasInertiaTensorReducedNoniterative": Property("ProjectedGasInertiaTensorReducedNoniterative", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the gas mass distribution in projection (reduced, from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
+    "ProjectedStellarInertiaTensor": Property("ProjectedStellarInertiaTensor", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the stellar mass distribution in projection (computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedStellarInertiaTensorReduced": Property("ProjectedStellarInertiaTensorReduced", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the stellar mass distribution in projection (reduced, computed iteratively): (1,1), (2,2), (1,2)."),
+    "ProjectedStellarInertiaTensorNoniterative": Property("ProjectedStellarInertiaTensorNoniterative", 3, np.float32, "snap_length**2", True, 2, False, 2, "2D inertia tensor of the stellar mass distribution in projection (from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
+    "ProjectedStellarInertiaTensorReducedNoniterative": Property("ProjectedStellarInertiaTensorReducedNoniterative", 3, np.float32, "dimensionless", True, 0, False, 0, "2D inertia tensor of the stellar mass distribution in projection (reduced, from the bound particles inside the projected aperture): (1,1), (2,2), (1,2)."),
     "ExSituFraction": Property("ExSituFraction", 1, np.float32, "dimensionless", True, 0, True, 0, "Mass fraction of bound stars that formed in a different subhalo (zero without stars)."),
     "kappa_corot_gas": Property("KappaCorotGas", 1, np.float32, "dimensionless", True, 0, False, 0, "Kinetic energy fraction of the gas in ordered co-rotation (Correa et al. 2017)."),
     "kappa_corot_star": Property("KappaCorotStars", 1, np.float32, "dimensionless", True, 0, False, 0, "Kinetic energy fraction of the stars in ordered co-rotation."),

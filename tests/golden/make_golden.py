@@ -326,7 +326,9 @@ def main():
             sp = PJ.SingleProjectionProjectedApertureParticleData(pp, proj)
             for name in ["Mtot", "Mdm", "Ndm", "Ngas", "Nstar", "Nbh", "com", "vcom", "HalfMassRadiusDM",
                          "proj_veldisp_dm", "com_star", "proj_veldisp_gas", "proj_veldisp_star",
-                         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon"]:
+                         "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
+                         *[f"Projected{c}InertiaTensor{s}" for c in ("Total", "Gas", "Stellar")
+                           for s in ("", "Reduced", "Noniterative", "ReducedNoniterative")]]:
                 val = getattr(sp, name)
                 case[f"PJ/{proj}/{name}"] = np.array(np.nan) if val is None else np.asarray(val, dtype=np.float64)
         cases.append(case)

@@ -153,7 +153,7 @@ def test_particle_data_classes_match_reference():
     reference, property by property, on random single- and multi-type halos."""
     g = np.load(os.path.join(GOLD, "particle_data_classes.npz"))
     u0 = _units(g)
-    n_so = n_ap = n_nu = n_flow = n_short = n_rot = n_inertia = 0
+    n_so = n_ap = n_nu = n_flow = n_short = n_rot = n_inertia = n_pj_inertia = 0
     for i in range(int(g["ncases"])):
         c, data = _case(g, i)
         u = dataclasses.replace(u0, nu_density=float(c["nu_density"]))
@@ -250,4 +250,12 @@ def test_particle_data_classes_match_reference():
                                                 "HalfMassRadiusDM", "proj_veldisp_dm", "com_star",
                                                 "proj_veldisp_gas", "proj_veldisp_star", "HalfMassRadiusGas",
                                                 "HalfMassRadiusStar", "HalfMassRadiusBaryon"])  # fmt: skip
-    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20 and n_rot > 150 and n_inertia > 300
+            for key in ho.PROJECTED_INERTIA_KEYS:   # 2D inertia tensors: same np.linalg.eigh, agree to rounding
+                want = c[f"PJ/{proj}/{key}"]
+                got = outs[proj].get(key)
+                if np.all(np.isnan(want)):
+                    assert got is None or np.all(np.asarray(got) == 0), (proj, key, got)
+                else:
+                    assert np.allclose(got, want, rtol=1e-11, atol=1e-13 * np.abs(want).max()), (proj, key, got, want)
+                    n_pj_inertia += 1
+    assert n_so > 20 and n_ap > 40 and n_nu > 8 and n_flow > 15 and n_short > 20 and n_rot > 150 and n_inertia > 300 and n_pj_inertia > 100

@@ -311,6 +311,11 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
                 for r in results for grp in ("BoundSubhalo", "SO/200_crit")
                 for key in ("GasInertiaTensor", "StellarInertiaTensorReduced", "GasInertiaTensorNoniterative"))
     assert ntens > 100
+    # 2D tensors of the projected apertures, per projection axis
+    npj = sum(int(np.any(r[f"ProjectedAperture/100kpc/{proj}/{key}"][4]))
+              for r in results for proj in ("projx", "projy", "projz")
+              for key in ("ProjectedTotalInertiaTensor", "ProjectedGasInertiaTensorReduced", "ProjectedStellarInertiaTensorNoniterative"))
+    assert npj > 300
     engine.close()
 
 
