@@ -7,15 +7,15 @@
 //   SOAP/particle_selection/SO_properties.py   :80-217, :313-513, :532-692, :857-913, :2725-2765
 //   SOAP/particle_selection/aperture_properties.py :270-317, :1099-1281, :3469-3577, :4024-4244
 //   SOAP/particle_selection/subhalo_properties.py  :128-164, :798-846, :982-1073, :2587-2740
-//   SOAP/property_calculation/{half_mass_radius,kinematic_properties}.py
+//   SOAP/property_calculation/{half_mass_radius,kinematic_properties,inertia_tensors}.py
 //
 // Design (DESIGN.md has the long form):
 //   * the COORDINATES of each type are physically reordered into mesh-cell order (SoA in HBM) so the cells a
 //     search sphere overlaps are a few contiguous runs -> coalesced reads; velocities, masses and ids stay in
 //     the caller's arrays and are gathered through the permutation for the particles a halo selects;
 //   * one thread group per halo -- a wavefront, 256 or 1024 threads, chosen from a cheap work estimate -- in
-//     three persistent kernels (halo_kernel.inc compiled three times) that run concurrently on priority
-//     streams and pull halos heaviest-first from device queues;
+//     three persistent kernels (halo_kernel.inc compiled per class, once more with the inertia tensor passes)
+//     that run concurrently on priority streams and pull halos heaviest-first from device queues;
 //   * per halo: stream candidate runs, exact periodic distance test, compact the selected particles into
 //     the group's slab, sort by radius (LDS bitonic / sample sort), ONE sequential fp64 cumulative-mass chain
 //     (bit-identical to numpy.cumsum, so SO radii and hence SO membership are reproducible); the reference's
