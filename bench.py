@@ -86,7 +86,8 @@ def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
 
     L = sc.boxsize
     n = sum(int(d["Coordinates"].shape[0]) for d in data.values())
-    frac = min(1.0, (1.5e6 / n) ** (1.0 / 3.0))
+    # about 3e6 particles: 10-20 s of oracle work on one core for the C3 / C5 property sets (bounded by budget_s)
+    frac = min(1.0, (3.0e6 / n) ** (1.0 / 3.0))
     side = L * frac
     rr = halos["read_radius"]
     c = halos["cofp"]
