@@ -367,26 +367,79 @@ struct MeshGeom {
     int res;
 };
 
-// cell index of every particle + histogram (shared_mesh.py:69-80).  The histogram's atomic add returns the
+// cell index of every particle + histogram (shared_mesh.py:69-80).  The histogram's returning add gives the
 // number of particles that entered the cell before: that is the particle's rank inside its cell, so the
-// placement pass needs no second round of atomics.
+// placement pass needs no second round of atomics.  Adds are aggregated twice: lanes of a wavefront with the
+// same cell share one LDS add, and the cells touched by a block's 256 consecutive particles (snapshots are
+// stored by top-level cell, so they are few) share one global add each through a small LDS hash table.
+#define CELL_SLOTS 512
+#define CELL_EMPTY 0xffffffffu
 __global__ void k_cellid(const double *pos, long long n, MeshGeom g, unsigned *cell,
                          unsigned *count, unsigned *rank) {
-    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
-         i += (long long)gridDim.x * BLK) {
-        int c[3];
+    __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_base[CELL_SLOTS];
+    for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * BLK;
+    const long long niter = (n + stride - 1) / stride;
+    for (long long it = 0; it < niter; it++) {
+        const long long i = it * stride + blockIdx.x * (long long)BLK + threadIdx.x;
+        const bool active = i < n;
+        unsigned id = 0;
+        if (active) {
+            int c[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            double q = floor((pos[3 * i + d] - g.pos_min[d]) / g.cell_size[d]);
-            // .astype(np.int32) then np.clip(0, res-1)
-            int ci = (q >= 2147483647.0) ? 2147483647 : (q <= -2147483648.0 ? (-2147483647 - 1) : (int)q);
-            ci = ci < 0 ? 0 : (ci > g.res - 1 ? g.res - 1 : ci);
-            c[d] = ci;
+            for (int d = 0; d < 3; d++) {
+                double q = floor((pos[3 * i + d] - g.pos_min[d]) / g.cell_size[d]);
+                // .astype(np.int32) then np.clip(0, res-1)
+                int ci = (q >= 2147483647.0) ? 2147483647 : (q <= -2147483648.0 ? (-2147483647 - 1) : (int)q);
+                ci = ci < 0 ? 0 : (ci > g.res - 1 ? g.res - 1 : ci);
+                c[d] = ci;
+            }
+            id = (unsigned)c[0] + (unsigned)g.res * (unsigned)c[1] + (unsigned)g.res * (unsigned)g.res * (unsigned)c[2];
+            cell[i] = id;
         }
-        unsigned id = (unsigned)c[0] + (unsigned)g.res * (unsigned)c[1] +
-                      (unsigned)g.res * (unsigned)g.res * (unsigned)c[2];
-        cell[i] = id;
-        rank[i] = wave_agg_inc<true>(count, id, true);
+        // ---- wavefront level: groups of lanes with the same cell (up to 4 groups, the rest go alone)
+        unsigned long long todo = __ballot(active);
+        bool mine = active;
+        int my_leader = -1, my_rank = 0, my_cnt = 0;
+        for (int round = 0; round < 4 && todo; round++) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)id, leader);
+            const bool in = mine && id == k0;
+            const unsigned long long grp = __ballot(in);
+            if (in) {
+                my_leader = leader;
+                my_rank = __popcll(grp & ((1ull << lane) - 1ull));
+                my_cnt = __popcll(grp);
+                mine = false;
+            }
+            todo &= ~grp;
+        }
+        const bool adds = my_leader == lane || mine;   // this lane adds for its group (or for itself)
+        // ---- block level: one slot per distinct cell in an open-addressing LDS table, LDS add returns the group's base
+        unsigned slot = 0, lbase = 0;
+        if (adds) {
+            unsigned hsh = (id * 2654435761u) >> 23;   // 9 bits
+            while (true) {
+                const unsigned prev = atomicCAS(&s_key[hsh], CELL_EMPTY, id);
+                if (prev == CELL_EMPTY || prev == id) break;
+                hsh = (hsh + 1u) & (CELL_SLOTS - 1);
+            }
+            slot = hsh;
+            lbase = atomicAdd(&s_cnt[slot], my_leader == lane ? (unsigned)my_cnt : 1u);
+        }
+        __syncthreads();
+        // ---- one global add per distinct cell of the block
+        for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK)
+            if (s_key[t] != CELL_EMPTY) s_base[t] = atomicAdd(&count[s_key[t]], s_cnt[t]);
+        __syncthreads();
+        unsigned base = adds ? s_base[slot] + lbase : 0u;
+        const unsigned lb = (unsigned)__shfl((int)base, my_leader >= 0 ? my_leader : lane, 64);
+        if (active) rank[i] = my_leader >= 0 ? lb + (unsigned)my_rank : base;
+        __syncthreads();
+        for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; }
+        __syncthreads();
     }
 }
 
