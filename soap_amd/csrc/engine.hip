@@ -503,20 +503,75 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_n;
 }
 
-// Placement: particle i goes to slot offset[cell] + rank of its cell (order inside a cell is arbitrary: it only
+// Placement: particle i goes to slot p = offset[cell] + rank of its cell (order inside a cell is arbitrary: it only
 // feeds candidate streaming; everything order-sensitive happens after the radial sort) and its position is
 // written there (AoS input read in order -> SoA output in cell order), so no second pass has to gather the
 // coordinates back through sort_idx.  Velocities, masses and ids stay where the caller put them: only
 // selected particles ever need them, and those are gathered through `orig` when a halo's slab is built.
+// k_cellid gave the particles of one cell inside one block iteration CONSECUTIVE ranks (one global add per
+// cell and block), so their destinations are one run: the block first regroups its 256 particles by
+// destination run in LDS (hash table: run start and length per cell, prefix over the table), then consecutive
+// threads store to consecutive addresses -- four coalesced streams instead of four scattered 8-byte stores
+// per particle.  Launched with the grid of k_cellid (same particles per block iteration).
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
                               unsigned *sort_idx, const double *pos, double *x, double *y, double *z) {
-    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n;
-         i += (long long)gridDim.x * BLK) {
-        const unsigned c = cell[i];
-        const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
-        const long long p = (long long)offset[c] + rank[i];
-        sort_idx[p] = (unsigned)i;
-        x[p] = px; y[p] = py; z[p] = pz;
+    __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
+    __shared__ unsigned s_wsum[BLK / 64], s_total;
+    __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
+    __shared__ unsigned s_i[BLK], s_p[BLK];
+    for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long stride = (long long)gridDim.x * BLK;
+    const long long niter = (n + stride - 1) / stride;
+    for (long long it = 0; it < niter; it++) {
+        const long long i = it * stride + blockIdx.x * (long long)BLK + threadIdx.x;
+        const bool active = i < n;
+        unsigned c = 0, p = 0, slot = 0;
+        double px = 0.0, py = 0.0, pz = 0.0;
+        if (active) {
+            c = cell[i];
+            px = pos[3 * i]; py = pos[3 * i + 1]; pz = pos[3 * i + 2];
+            p = offset[c] + rank[i];
+            unsigned hsh = (c * 2654435761u) >> 23;
+            while (true) {
+                const unsigned prev = atomicCAS(&s_key[hsh], CELL_EMPTY, c);
+                if (prev == CELL_EMPTY || prev == c) break;
+                hsh = (hsh + 1u) & (CELL_SLOTS - 1);
+            }
+            slot = hsh;
+            atomicMin(&s_min[slot], p);
+            atomicAdd(&s_cnt[slot], 1u);
+        }
+        __syncthreads();
+        // exclusive prefix of the run lengths over the table (two slots per thread)
+        {
+            const unsigned a0 = s_cnt[2 * threadIdx.x], a1 = s_cnt[2 * threadIdx.x + 1];
+            unsigned v = a0 + a1;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned u = (unsigned)__shfl_up((int)v, o, 64); if (lane >= o) v += u; }
+            if (lane == 63) s_wsum[wv] = v;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < wv; w++) wbase += s_wsum[w];
+            const unsigned excl = wbase + v - (a0 + a1);
+            s_off[2 * threadIdx.x] = excl; s_off[2 * threadIdx.x + 1] = excl + a0;
+            if (threadIdx.x == BLK - 1) s_total = excl + a0 + a1;
+        }
+        __syncthreads();
+        if (active) {
+            unsigned li = s_off[slot] + (p - s_min[slot]);
+            li = li < BLK ? li : BLK - 1;   // cannot happen with the launch contract above
+            s_x[li] = px; s_y[li] = py; s_z[li] = pz; s_i[li] = (unsigned)i; s_p[li] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x < s_total) {
+            const unsigned q = s_p[threadIdx.x];
+            sort_idx[q] = s_i[threadIdx.x];
+            x[q] = s_x[threadIdx.x]; y[q] = s_y[threadIdx.x]; z[q] = s_z[threadIdx.x];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
+        __syncthreads();
     }
 }
 
