@@ -981,9 +981,13 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
 }
 
 static void free_halos(soap_engine *h) {
-    void *ptrs[] = {h->d_cofp, h->d_search, h->d_read, h->d_index, h->d_nrbound, h->d_stats,
-                    h->d_central, h->d_status, h->d_todo};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    // back into the handle's pool: the next chunk's catalogue usually has the same size (hipMalloc / hipFree of
+    // nine arrays cost ~0.8 ms per staging)
+    const size_t n = (size_t)h->n_halo;
+    std::pair<void *, size_t> ptrs[] = {{h->d_cofp, n * 24}, {h->d_search, n * 8}, {h->d_read, n * 8}, {h->d_index, n * 8},
+                                        {h->d_nrbound, n * 8}, {h->d_stats, n * 32}, {h->d_central, n * 4},
+                                        {h->d_status, n * 4}, {h->d_todo, n * 4}};
+    for (auto &p : ptrs) if (p.first) h->pool.release(p.first, p.second);
     h->d_cofp = h->d_search = h->d_read = nullptr;
     h->d_index = h->d_nrbound = h->d_stats = nullptr;
     h->d_central = h->d_status = h->d_todo = nullptr;
@@ -995,8 +999,8 @@ int32_t soap_engine_destroy(soap_engine *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     for (int t = 0; t < NT_ALL; t++) h->t[t].release(h->pool);
-    h->pool.purge();
     free_halos(h);
+    h->pool.purge();
     free_slabs(h);
     for (int k = 0; k < 3; k++) {
         if (h->cls[k].d_queue) (void)hipFree(h->cls[k].d_queue);
@@ -1187,15 +1191,15 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n, const double *cofp,
         if (!(search_radius[i] > 0.0) || !(read_radius[i] >= search_radius[i]))
             return fail(-4, "need 0 < search_radius <= read_radius (halo_tasks.py:78)");
     }
-    HIPCHECK(hipMalloc((void **)&h->d_cofp, (size_t)n * 24));
-    HIPCHECK(hipMalloc((void **)&h->d_search, (size_t)n * 8));
-    HIPCHECK(hipMalloc((void **)&h->d_read, (size_t)n * 8));
-    HIPCHECK(hipMalloc((void **)&h->d_index, (size_t)n * 8));
-    HIPCHECK(hipMalloc((void **)&h->d_nrbound, (size_t)n * 8));
-    HIPCHECK(hipMalloc((void **)&h->d_stats, (size_t)n * 32));
-    HIPCHECK(hipMalloc((void **)&h->d_central, (size_t)n * 4));
-    HIPCHECK(hipMalloc((void **)&h->d_status, (size_t)n * 4));
-    HIPCHECK(hipMalloc((void **)&h->d_todo, (size_t)n * 4));
+    HIPCHECK(h->pool.alloc((void **)&h->d_cofp, (size_t)n * 24));
+    HIPCHECK(h->pool.alloc((void **)&h->d_search, (size_t)n * 8));
+    HIPCHECK(h->pool.alloc((void **)&h->d_read, (size_t)n * 8));
+    HIPCHECK(h->pool.alloc((void **)&h->d_index, (size_t)n * 8));
+    HIPCHECK(h->pool.alloc((void **)&h->d_nrbound, (size_t)n * 8));
+    HIPCHECK(h->pool.alloc((void **)&h->d_stats, (size_t)n * 32));
+    HIPCHECK(h->pool.alloc((void **)&h->d_central, (size_t)n * 4));
+    HIPCHECK(h->pool.alloc((void **)&h->d_status, (size_t)n * 4));
+    HIPCHECK(h->pool.alloc((void **)&h->d_todo, (size_t)n * 4));
     hipStream_t st = h->stream;
     HIPCHECK(hipMemcpyAsync(h->d_cofp, cofp, (size_t)n * 24, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(h->d_search, search_radius, (size_t)n * 8, hipMemcpyHostToDevice, st));
