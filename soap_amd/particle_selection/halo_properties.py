@@ -80,6 +80,11 @@ class HaloProperty:
 
     # ---- properties enabled for this run --------------------------------------------
     def enabled_properties(self):
+        # fixed once the calculation is constructed (property filters and the DMO switch do not change): cached,
+        # process_halos asks for it several times per calculation and call
+        cached = getattr(self, "_enabled", None)
+        if cached is not None:
+            return cached
         dmo = bool(self.category_filter is not None and self.category_filter.dmo)
         out = []
         for key in self.property_names:
@@ -91,7 +96,8 @@ class HaloProperty:
             if key in layout.VIRTUAL_ZERO_KEYS and not dmo:
                 continue
             out.append(key)
-        return out
+        self._enabled = tuple(out)
+        return self._enabled
 
     # ---- the reference's per-halo operator protocol ------------------------------------------
     def bind(self, batch, position: int):
