@@ -11,5 +11,5 @@ CMD="python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- $CMD > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > $OUT/write.log 2>&1 || exit 1
-python3 bench.py --workload c3 --steps 3 --warmup 1 > $OUT/bench_c3.json 2> $OUT/bench_c3.err || exit 1
+python3 bench.py --workload c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err || exit 1
 tail -1 $OUT/bench_c3.json | cut -c1-400
