@@ -152,10 +152,12 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     todo = np.flatnonzero(np.asarray(halo_arrays["done"]) == 0)
     calcs = [hp.calc_desc(halo_prop_list, i) for i, hp in enumerate(halo_prop_list)]
     target_density = target_density_of(halo_prop_list, cellgrid)
+    # first pass over a chunk: every halo is still to do, the catalogue arrays go in as they are
+    pick = (lambda a: np.asarray(a)) if todo.size == len(halo_arrays["done"]) else (lambda a: np.asarray(a)[todo])
     engine.stage_halos(
-        halo_arrays["cofp"][todo], halo_arrays["search_radius"][todo],
-        halo_arrays["read_radius"][todo], halo_arrays["index"][todo],
-        halo_arrays["is_central"][todo], halo_arrays["nr_bound_part"][todo],
+        pick(halo_arrays["cofp"]), pick(halo_arrays["search_radius"]),
+        pick(halo_arrays["read_radius"]), pick(halo_arrays["index"]),
+        pick(halo_arrays["is_central"]), pick(halo_arrays["nr_bound_part"]),
     )  # fmt: skip
     t0_task = time.time()
     engine.run(calcs, target_density)
