@@ -1,0 +1,154 @@
+"""
+Halo -> chunk assignment: the counterpart of `peano_decomposition`
+(SOAP/core/domain_decomposition.py:9-142).
+
+The reference sorts the halo centres by their Peano-Hilbert key on a 1024^3 grid
+(10 bits per dimension, :66-85) with `virgo.util.peano.peano_hilbert_keys` and cuts the
+sorted list into `nr_chunks` runs of (almost) equal length (:135-140: the first
+`total % nr_chunks` chunks get one halo more).  `virgo` is a third-party package that
+is not part of the reference tree (virgodc>=1.0.3, requirements.txt:9); its key is the
+Gadget-2 Peano-Hilbert key, whose published algorithm (Springel 2005, Gadget-2 `peano.c`:
+a rotation state machine over octants, three bits of key per level) is restated here and
+pinned by the defining properties of the curve in tests/test_domain_decomposition.py:
+the key is a bijection on the 2^bits cube, cells with consecutive keys are face neighbours,
+and the curve starts in the cell (0, 0, 0).
+
+`separate_chunks` (:29-62, :96-133: halos with more bound particles than a threshold are
+taken out of the curve order and put on chunks of their own, most massive first) is
+reproduced as well, because it decides which GPU gets the giants.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# Gadget-2 peano.c: octant -> position along the curve for each of the 24 orientations of the
+# Hilbert cell ([rotation][bitx][bity][bitz]), and how the orientation changes when the curve
+# descends into that octant (number of quarter turns about x, then about y; mirror or not).
+_QUADRANTS = np.array([
+    # rotx = 0, roty = 0..3
+    [[[0, 7], [1, 6]], [[3, 4], [2, 5]]],
+    [[[7, 4], [6, 5]], [[0, 3], [1, 2]]],
+    [[[4, 3], [5, 2]], [[7, 0], [6, 1]]],
+    [[[3, 0], [2, 1]], [[4, 7], [5, 6]]],
+    # rotx = 1, roty = 0..3
+    [[[1, 0], [6, 7]], [[2, 3], [5, 4]]],
+    [[[0, 3], [7, 4]], [[1, 2], [6, 5]]],
+    [[[3, 2], [4, 5]], [[0, 1], [7, 6]]],
+    [[[2, 1], [5, 6]], [[3, 0], [4, 7]]],
+    # rotx = 2, roty = 0..3
+    [[[6, 1], [7, 0]], [[5, 2], [4, 3]]],
+    [[[1, 2], [0, 3]], [[6, 5], [7, 4]]],
+    [[[2, 5], [3, 4]], [[1, 6], [0, 7]]],
+    [[[5, 6], [4, 7]], [[2, 1], [3, 0]]],
+    # rotx = 3, roty = 0..3
+    [[[7, 6], [0, 1]], [[4, 5], [3, 2]]],
+    [[[6, 5], [1, 2]], [[7, 4], [0, 3]]],
+    [[[5, 4], [2, 3]], [[6, 7], [1, 0]]],
+    [[[4, 7], [3, 0]], [[5, 6], [2, 1]]],
+    # rotx = 4, roty = 0..3
+    [[[6, 7], [5, 4]], [[1, 0], [2, 3]]],
+    [[[7, 0], [4, 3]], [[6, 1], [5, 2]]],
+    [[[0, 1], [3, 2]], [[7, 6], [4, 5]]],
+    [[[1, 6], [2, 5]], [[0, 7], [3, 4]]],
+    # rotx = 5, roty = 0..3
+    [[[2, 3], [1, 0]], [[5, 4], [6, 7]]],
+    [[[3, 4], [0, 7]], [[2, 5], [1, 6]]],
+    [[[4, 5], [7, 6]], [[3, 2], [0, 1]]],
+    [[[5, 2], [6, 1]], [[4, 3], [7, 0]]],
+], dtype=np.int64)  # fmt: skip
+_ROTXMAP = np.array([4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 17, 18, 19, 16, 23, 20, 21, 22])
+_ROTYMAP = np.array([1, 2, 3, 0, 16, 17, 18, 19, 11, 8, 9, 10, 22, 23, 20, 21, 14, 15, 12, 13, 4, 5, 6, 7])
+_ROTX = np.array([3, 0, 0, 2, 2, 0, 0, 1])
+_ROTY = np.array([0, 1, 1, 2, 2, 3, 3, 0])
+_SENSE = np.array([-1, -1, -1, +1, +1, -1, -1, -1])
+
+
+def _next_rotation_table():
+    """rotation after descending into octant `quad`: `rotx` quarter turns about x, then `roty` about y."""
+    nxt = np.zeros((24, 8), dtype=np.int64)
+    for rot in range(24):
+        for quad in range(8):
+            r = rot
+            for _ in range(_ROTX[quad]):
+                r = _ROTXMAP[r]
+            for _ in range(_ROTY[quad]):
+                r = _ROTYMAP[r]
+            nxt[rot, quad] = r
+    return nxt
+
+
+_NEXT_ROT = _next_rotation_table()
+
+
+def peano_hilbert_keys(ix, iy, iz, bits: int) -> np.ndarray:
+    """Peano-Hilbert key of integer cell coordinates in [0, 2^bits)^3 (vectorised over halos)."""
+    ix = np.asarray(ix, dtype=np.int64)
+    iy = np.asarray(iy, dtype=np.int64)
+    iz = np.asarray(iz, dtype=np.int64)
+    key = np.zeros(ix.shape, dtype=np.int64)
+    rotation = np.zeros(ix.shape, dtype=np.int64)
+    sense = np.ones(ix.shape, dtype=np.int64)
+    for level in range(bits - 1, -1, -1):
+        bx, by, bz = (ix >> level) & 1, (iy >> level) & 1, (iz >> level) & 1
+        quad = _QUADRANTS[rotation, bx, by, bz]
+        key = (key << 3) + np.where(sense == 1, quad, 7 - quad)
+        sense = sense * _SENSE[quad]
+        rotation = _NEXT_ROT[rotation, quad]
+    return key
+
+
+def peano_decomposition(boxsize: float, halo: Dict[str, np.ndarray], nr_chunks: int,
+                        separate_chunks: Optional[Sequence[Dict]] = None,
+                        bits_per_dimension: int = 10) -> Tuple[Dict[str, np.ndarray], np.ndarray]:  # fmt: skip
+    """
+    Order the halo table along the Peano-Hilbert curve and cut it into chunks of (almost) equal
+    halo count (domain_decomposition.py:64-142).  `halo` is a dict of NumPy arrays with at least
+    `cofp` (n, 3) and, when `separate_chunks` is given, `nr_bound_part`.
+    `separate_chunks`: list of {"n_bound_threshold": int, "n_halo_per_chunk": int} sorted by
+    decreasing threshold (parameter_file.py `separate_chunks`); halos above the smallest threshold
+    leave the curve and are appended in chunks of their own, most bound particles first.
+    Returns (halo table in chunk order, chunk_size array).
+    """
+    halo = {k: np.asarray(v) for k, v in halo.items()}
+    total_nr_halos = halo["cofp"].shape[0]
+    large = None
+    if separate_chunks:
+        n_bound_threshold = separate_chunks[-1]["n_bound_threshold"]
+        large_mask = halo["nr_bound_part"] > n_bound_threshold
+        if np.any(large_mask):
+            large = {k: v[large_mask] for k, v in halo.items()}
+            halo = {k: v[~large_mask] for k, v in halo.items()}
+    centres = halo["cofp"]
+    cells_per_dimension = 2**bits_per_dimension
+    grid_size = boxsize / cells_per_dimension
+    total_nr_small_halos = centres.shape[0]
+    nr_chunks = max(1, min(nr_chunks, total_nr_small_halos)) if total_nr_small_halos else 0
+    ipos = np.floor(centres / grid_size).astype(np.int64)
+    ipos = np.clip(ipos, 0, cells_per_dimension - 1)
+    phkey = peano_hilbert_keys(ipos[:, 0], ipos[:, 1], ipos[:, 2], bits_per_dimension)
+    order = np.argsort(phkey, kind="stable")
+    halo = {k: v[order] for k, v in halo.items()}
+    large_halo_chunk_size: List[int] = []
+    if large is not None:
+        argsort = np.argsort(large["nr_bound_part"], kind="stable")[::-1]
+        large = {k: v[argsort] for k, v in large.items()}
+        nr_large = large["cofp"].shape[0]
+        i_threshold = 0
+        i_halo = 0
+        while i_halo < nr_large:
+            while separate_chunks[i_threshold]["n_bound_threshold"] > large["nr_bound_part"][i_halo]:
+                i_threshold += 1
+            c = min(separate_chunks[i_threshold]["n_halo_per_chunk"], nr_large - i_halo)
+            large_halo_chunk_size.append(c)
+            i_halo += c
+        halo = {k: np.concatenate([halo[k], large[k]], axis=0) for k in halo}
+    chunk_size = np.zeros(nr_chunks + len(large_halo_chunk_size), dtype=np.int64)
+    if nr_chunks:
+        chunk_size[:nr_chunks] = total_nr_small_halos // nr_chunks
+        chunk_size[: total_nr_small_halos % nr_chunks] += 1
+    chunk_size[nr_chunks:] = large_halo_chunk_size
+    assert np.sum(chunk_size) == total_nr_halos
+    return halo, chunk_size
