@@ -6,16 +6,26 @@ bench.py -- headline benchmark of the halo-property engine (BASELINE.json).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): BASELINE.json configs[2], the one the north-star target is
-quoted on -- synthetic DMO chunk, 1e8 particles / 1e5 halos, BoundSubhalo + the 9 default SO
-definitions + inclusive/exclusive 30/50/100 kpc spheres (16 calculations), fp64, one chunk per
-GPU.  `--workload c2` selects configs[1] (1e7 / 1e4, SO_200_crit only).
+quoted on -- synthetic DMO box, 1e8 particles / 1e5 halos, BoundSubhalo + the 9 default SO
+definitions + inclusive/exclusive 30/50/100 kpc spheres (16 calculations), fp64.
+`--workload c2` selects configs[1] (1e7 / 1e4, SO_200_crit only), `c5` the hydro chunk.
 
-A "step" is one pass of the hot path over the chunk with the raw particle arrays already
-resident in HBM: mesh build + reorder into cell order (soap_engine_stage_particles) and
-process_halos (soap_engine_run) -- SURVEY.md section 8(d).  Multi-GPU: weak scaling, one chunk per
-rank, no data-path collective; the per-rank result tables are concatenated with ONE RCCL
-all-gather (the catalogue gather that replaces combine_chunks' parallel sort), inside the
-timed region.
+One PASS over the box = what ChunkTask.__call__ does for a chunk whose particles are already
+resident in HBM (SOAP/core/chunk_tasks.py:189-367): mesh build + reorder into cell order
+(soap_engine_stage_particles) and process_halos (soap_engine_run), repeated for the halos that
+come back with a larger read radius (halo_tasks.py:393-402) until none is left -- the retry passes
+are inside the timed region.  A timed STEP is `--passes-per-step` (default 8) consecutive passes,
+so that the driver's 20 steps keep the GPU busy for several seconds; `ms_per_pass` is the
+round-1 "ms_per_step".
+
+Multi-GPU (BASELINE.json configs[3]): STRONG scaling, the SAME seed-1234 box on every N.  The halos are cut
+into N Peano-Hilbert chunks (soap_amd/core/domain_decomposition.py), rank g gets chunk g and every particle
+of the top-level cells its halos' read spheres overlap (boundary cells replicated, no particle exchange:
+soap_amd/core/chunk_tasks.py), read once before the timed region (the stand-in of the snapshot read); the
+per-rank result tables are concatenated and put in final-catalogue order by `gather_catalogue` (ONE
+all-gather over RCCL/xGMI plus a device sort) inside the timed region.  Until the driver's SCALE run
+exists there is no hardware scaling curve; `replication` in the line says how many particles the chunks
+hold together relative to the box.
 
 metric = particle-aperture evaluations per second: E = sum_h n_sel(h) * A, n_sel = particles in
 the halo's final search sphere, A = number of calculations.
@@ -35,16 +45,22 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 B_PARTICLE = 68  # x,y,z,vx,vy,vz,m fp64 + GroupNr_bound i32 + FOFGroupIDs i64
+TOPCELLS = 16    # top-level cells per dimension of the synthetic snapshot (soap_amd/synthetic.py)
 
 WORKLOADS = {
     "c3": dict(n_part=100_000_000, n_halo=100_000, so="default", apertures=(30.0, 50.0, 100.0),
-               name="synthetic DMO 1e8 particles / 1e5 halos, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc"),
+               name="synthetic DMO 1e8 particles / 1e5 halos, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc; "
+                    "inertia tensors off; halo sizes capped at 3e5 particles"),
     "c2": dict(n_part=10_000_000, n_halo=10_000, so="200_crit", apertures=(),
-               name="synthetic DMO 1e7 particles / 1e4 halos, BoundSubhalo + SO_200_crit"),
+               name="synthetic DMO 1e7 particles / 1e4 halos, BoundSubhalo + SO_200_crit; "
+                    "inertia tensors off; halo sizes capped at 3e5 particles"),
     "c5": dict(n_part=25_000_000, n_halo=25_000, so="default", apertures=(30.0, 50.0, 100.0),
                projected=(10.0, 30.0, 50.0, 100.0), hydro=True,
-               name="synthetic hydro (gas+DM+stars+BH) 2.5e7 particles / 2.5e4 halos per GPU (2e8 on 8 GPUs), "
-                    "BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc + projected 10/30/50/100 kpc"),
+               name="synthetic hydro (gas+DM+stars+BH) 2.5e7 particles / 2.5e4 halos (the per-GPU share of 2e8 on 8 "
+                    "GPUs), BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc + projected 10/30/50/100 kpc; inertia tensors off"),
+    "giant": dict(n_part=20_000_000, n_halo=2_000, so="default", apertures=(30.0, 50.0, 100.0), max_halo=1_000_000,
+                  name="synthetic DMO 2e7 particles / 2e3 halos with the halo size cap lifted to 1e6 particles, "
+                       "C3 calculation list; inertia tensors off"),
     "tiny": dict(n_part=400_000, n_halo=400, so="default", apertures=(30.0, 50.0, 100.0),
                  name="synthetic DMO 4e5 particles / 4e2 halos (plumbing check)"),
 }  # fmt: skip
@@ -61,6 +77,9 @@ class _NamedPropertySet:
             return {n: "basic" for n in names}
         return {n: (False if "InertiaTensor" in n else "basic") for n in names}
 
+    def strict_halo_copy(self):
+        return False
+
 
 def build_props(sc, wl):
     from soap_amd import compute_halo_properties as chp
@@ -74,20 +93,67 @@ def build_props(sc, wl):
                                                                    parameters=_NamedPropertySet())
 
 
-def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
-    """Oracle (CPU restatement of the reference, one core) timed on a bounded sample of the
-    SAME chunk: the halos whose read sphere lies inside a sub-cube, with the particles of that
-    sub-cube copied to the host.  Only process_halos-equivalent work is timed."""
+# ---- CPU baseline: the oracle on the host cores ------------------------------------------------------------
+def _cpu_worker(wid, payload_path, counter, budget_s, out):
+    """One worker per core pulling halo numbers off a shared counter, biggest halos first
+    (halo_tasks.py:352-357, chunk_tasks.py:118-120).  Started with `spawn`: a fresh interpreter that only ever
+    imports NumPy / SciPy and the oracle -- nothing in it touches the GPU."""
+    import pickle
+
+    from oracle import halo_oracle as ho
+
+    with open(payload_path, "rb") as f:
+        g = pickle.load(f)
+    ho.ENABLE_INERTIA = g["inertia"]
+    n = len(g["h_np"]["index"])
+    with counter.get_lock():   # rendezvous: the clock starts when every worker has loaded the sample
+        counter.value += 1
+    while counter.value < g["nworkers"]:
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    evals = nh = 0
+    while True:
+        with counter.get_lock():
+            i = counter.value - g["nworkers"]
+            counter.value += 1
+        if i >= n or time.perf_counter() - t0 > budget_s:
+            break
+        ih = {k: v[i, ...].copy() for k, v in g["h_np"].items()}
+        st = {}
+        r = ho.process_single_halo(g["mesh"], g["d_np"], g["props"], g["u"], ih,
+                                   g["td"] if ih["is_central"] == 1 else None, st)  # fmt: skip
+        if r is not None:
+            evals += st["n_sel"] * g["A"]
+            nh += 1
+    out[wid] = (evals, nh, time.perf_counter() - t0)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
+    """Oracle (CPU restatement of the reference) timed on a bounded sample of the SAME box: the halos whose
+    read sphere lies inside a sub-cube, with the particles of that sub-cube copied to the host.  Only
+    process_halos-equivalent work is timed: first on one core, then with one worker per core of this
+    process' CPU share pulling halos from a shared counter."""
+    import multiprocessing as mp
+
     import torch
 
-    from soap_amd.core.category_filter import CategoryFilter
-    from tests import helpers
     from oracle import halo_oracle as ho
+    from tests import helpers
 
     L = sc.boxsize
     n = sum(int(d["Coordinates"].shape[0]) for d in data.values())
-    # about 3e6 particles: 10-20 s of oracle work on one core for the C3 / C5 property sets (bounded by budget_s)
-    frac = min(1.0, (3.0e6 / n) ** (1.0 / 3.0))
+    frac = min(1.0, (3.0e6 / n) ** (1.0 / 3.0))   # about 3e6 particles on the host
     side = L * frac
     rr = halos["read_radius"]
     c = halos["cofp"]
@@ -100,34 +166,62 @@ def cpu_baseline(sc, data, halos, wl, budget_s=20.0):
         psel = (d["Coordinates"] <= side).all(dim=1)
         d_np[pt] = {k: v[psel].cpu().numpy() for k, v in d.items()}
     h_np = {k: v[rows].cpu().numpy() for k, v in halos.items()}
+    order = np.argsort(h_np["nr_bound_part"])[::-1]
+    h_np = {k: v[order] for k, v in h_np.items()}
     cf, so_vars, ap_vars, pj_vars, _ = build_props(sc, wl)
     u, props = helpers.oracle_prop_list(sc, cf, so_vars, ap_vars, pj_vars)
-    ho.ENABLE_INERTIA = os.environ.get("BENCH_INERTIA") == "1"   # same property set as the engine run (_NamedPropertySet)
+    ho.ENABLE_INERTIA = os.environ.get("BENCH_INERTIA") == "1"   # same property set as the engine run
     npart = sum(d["Masses"].shape[0] for d in d_np.values())
     mesh = {}
     for pt, d in d_np.items():
         n_pt = int(data[pt]["Coordinates"].shape[0])
         mesh[pt] = ho.Mesh(d["Coordinates"], max(1, int(round(ho.mesh_resolution(n_pt) * frac))))
-    A = len(props)
-    td = ho.target_density_of(props, u)
-    t0 = time.perf_counter()
-    evals = 0
-    nh = 0
-    for i in range(len(h_np["index"])):
-        ih = {k: v[i, ...].copy() for k, v in h_np.items()}
-        st = {}
-        r = ho.process_single_halo(mesh, d_np, props, u, ih, td if ih["is_central"] == 1 else None, st)
-        if r is not None:
-            evals += st["n_sel"] * A
-            nh += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
+    import pickle
+    import tempfile
+
+    payload = dict(d_np=d_np, h_np=h_np, props=props, u=u, mesh=mesh, A=len(props), td=ho.target_density_of(props, u),
+                   inertia=os.environ.get("BENCH_INERTIA") == "1", nworkers=1)
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ctx = mp.get_context("spawn")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    tmpdir = tempfile.mkdtemp(prefix="soap_cpu_baseline_")
+    path = os.path.join(tmpdir, "sample.pkl")
+
+    def run(nworkers, budget):
+        payload["nworkers"] = nworkers
+        with open(path, "wb") as f:
+            pickle.dump(payload, f, protocol=4)
+        counter = ctx.Value("l", 0)
+        with ctx.Manager() as mgr:
+            out = mgr.dict()
+            ps = [ctx.Process(target=_cpu_worker, args=(w, path, counter, budget, out)) for w in range(nworkers)]
+            for p in ps:
+                p.start()
+            for p in ps:
+                p.join()
+            res = dict(out)
+        if len(res) != nworkers:
+            raise RuntimeError(f"{nworkers - len(res)} CPU baseline workers died")
+        dt = max(v[2] for v in res.values())
+        ev = sum(v[0] for v in res.values())
+        nh = sum(v[1] for v in res.values())
+        return ev / dt, nh / dt, nh, dt
+
+    try:
+        v1, h1, n1, t1 = run(1, budget_s * 0.5)
+        ncore = max(1, min(share, 64))
+        vN, hN, nN, tN = run(ncore, budget_s) if ncore > 1 else (v1, h1, n1, t1)
+    finally:
+        import shutil
+
+        shutil.rmtree(tmpdir, ignore_errors=True)
     return {
-        "value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-        "halos_per_s": nh / dt,
-        "sample": f"{nh} halos of the same chunk inside a {frac:.3f}L sub-cube ({npart} particles), "
-                  f"{dt:.1f} s of NumPy oracle on 1 core; the true reference adds unyt overhead",
+        "value": vN, "unit": "evals/s", "cores": ncore, "kind": "port", "halos_per_s": hN,
+        "one_core": {"value": v1, "halos_per_s": h1},
+        "host": {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "cpu_share_of_this_process": share},
+        "sample": f"{len(h_np['index'])} halos of the same box inside a {frac:.3f}L sub-cube ({npart} particles), biggest "
+                  f"first off a shared counter: {nN} halos in {tN:.1f} s on {ncore} worker processes ({n1} in {t1:.1f} s "
+                  f"on one); NumPy oracle, the true reference adds unyt overhead",
     }  # fmt: skip
 
 
@@ -136,6 +230,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--passes-per-step", type=int, default=8)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
@@ -157,6 +252,7 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
@@ -166,99 +262,120 @@ def main():
     import __graft_entry__ as g
 
     g.build()
-    from soap_amd.core import halo_tasks
+    from soap_amd.catalogue import gather_catalogue
+    from soap_amd.core import chunk_tasks, halo_tasks
     from soap_amd.synthetic import make_chunk
 
     wl = WORKLOADS[args.workload]
     t_gen = time.time()
-    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed + rank, device=f"cuda:{local_rank}",
-                                 hydro=wl.get("hydro", False))
+    # every rank builds the SAME box (same seed) and keeps its chunk's region of it
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed, device=dev, hydro=wl.get("hydro", False),
+                                 max_halo=wl.get("max_halo"))
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     cf, so_vars, ap_vars, pj_vars, props = build_props(sc, wl)
     A = len(props)
-    halos_np = {k: v.cpu().numpy() for k, v in halos.items()}
+    halos_all = {k: v.cpu().numpy() for k, v in halos.items()}
+    snapshot = chunk_tasks.SnapshotCells(data, sc.boxsize, (TOPCELLS,) * 3)
+    n_box = snapshot.nr_particles()
+    if world > 1:
+        halos_np = chunk_tasks.split_halos(halos_all, sc.boxsize, world)[rank]
+        region, _, mask0 = chunk_tasks.read_chunk(snapshot, halos_np, wrap=True, return_mask=True)
+        # how far the cells this rank read are complete around each of its halos: read-radius updates that stay
+        # inside need no re-read (soap_engine_set_resident_radius)
+        resident0 = chunk_tasks.resident_radius(mask0, snapshot.cell_size, halos_np["cofp"], halos_np["read_radius"])
+        torch.cuda.synchronize()
+    else:
+        halos_np = halos_all
+        region = data
+        resident0 = np.full(len(halos_np["index"]), np.inf)   # the whole periodic box is resident
     H = len(halos_np["index"])
+    n_region = sum(int(d["Coordinates"].shape[0]) for d in region.values())
+    cell_size = snapshot.cell_size
+    d_cofp = torch.as_tensor(halos_np["cofp"], device=dev)
+    d_index = torch.as_tensor(halos_np["index"], device=dev)
 
     engine = halo_tasks.make_engine(sc, device=local_rank)
-    ncols_total = None
-    gathered = None
+    state = dict(nleft=0, npass=0, ncols=None, raw=None, catalogue=None, table=None)
+    ms_halo, ms_mesh, ms_reorder = [], [], []
 
-    # catalogue gather over xGMI: one all-gather of the (equal-sized) result tables per step.  Chunks are
-    # independent, so the gather of step k runs (async, on RCCL's stream, double-buffered) while step k+1
-    # stages and processes its chunk; every gather is complete before the timed region ends (sync()).
-    pending = [None, None]
-    bufs = [None, None]
-    k_step = 0
-
-    def step():
-        nonlocal ncols_total, gathered, k_step
-        halo_tasks.stage_chunk(engine, data)
+    def one_pass(record):
+        """ChunkTask loop for the resident region: stage, process, and again for the halos that need a larger
+        read radius (their cells are read again, chunk_tasks.py:189-367)."""
         ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
-        out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
-        raw = out[4]
-        if world > 1:
-            nc = engine.row_columns
-            b = k_step % 2
-            if pending[b] is not None:
-                pending[b].wait()
-            if bufs[b] is None:
-                bufs[b] = (torch.empty(H * nc, dtype=torch.float64, device=f"cuda:{local_rank}"),
-                           torch.empty(world * H * nc, dtype=torch.float64, device=f"cuda:{local_rank}"))
-            engine.copy_table_to(bufs[b][0])
-            pending[b] = dist.all_gather_into_tensor(bufs[b][1], bufs[b][0], async_op=True)
-            gathered = bufs[b][1]
-            k_step += 1
-        return raw, out[2]
+        cur, resident = region, resident0
+        stats = np.zeros((H, 4), dtype=np.int64)
+        status = np.full(H, -99, dtype=np.int32)
+        table = state["table"]
+        t_h = 0.0
+        for it in range(8):
+            halo_tasks.stage_chunk(engine, cur)
+            if it == 0 and record:
+                ms_mesh.append(engine.kernel_ms("mesh"))
+                ms_reorder.append(engine.kernel_ms("reorder"))
+            out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False, resident_radius=resident)
+            raw = out[4]
+            t_h += engine.kernel_ms("halo")
+            rows = raw["rows"]
+            okm = raw["status"] == 0
+            stats[rows[okm]] = raw["stats"][okm]
+            status[rows] = raw["status"]
+            if table is None:
+                state["ncols"] = engine.row_columns
+                table = state["table"] = torch.zeros((H, state["ncols"]), dtype=torch.float64, device=dev)
+            # finished rows into this pass' catalogue table (device to device)
+            if rows.size == H:
+                engine.copy_table_to(table.view(-1))
+            else:
+                part = torch.empty((rows.size, state["ncols"]), dtype=torch.float64, device=dev)
+                engine.copy_table_to(part.view(-1))
+                sel = torch.as_tensor(rows[okm], device=dev)
+                table[sel] = part[torch.as_tensor(np.flatnonzero(okm), device=dev)]
+            state["npass"] += 1
+            if out[2] == 0:
+                break
+            cur, _, mk = chunk_tasks.read_chunk(snapshot, ha, wrap=world > 1, return_mask=True)
+            resident = chunk_tasks.resident_radius(mk, snapshot.cell_size, ha["cofp"], ha["read_radius"])
+        if record:
+            ms_halo.append(t_h)
+        state["nleft"] = int(np.sum(ha["done"] == 0))
+        state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
+                            radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
+        # final catalogue: concatenation over the ranks in (cell, catalogue index) order
+        state["catalogue"] = gather_catalogue(table, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
 
     def sync():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Catalogue radii in their steady state: halos whose calculations need a larger region than the catalogue's
-    # read radius come back with new radii (halo_tasks.py:393-402) and are re-run, as ChunkTask does
-    # (chunk_tasks.py:306-340).  Done once here, untimed, so that every timed step finishes every halo in one
-    # pass (a handful of 1e5: the outer flow-rate shell of a low-density SO reaches past the read radius).
-    ha0 = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
-    halo_tasks.stage_chunk(engine, data)
-    for _ in range(6):
-        if halo_tasks.process_halos(engine, props, sc, ha0, None, unpack=False)[2] == 0:
-            break
-    n_radius_updates = int(np.sum(ha0["read_radius"] != halos_np["read_radius"]))
-    halos_np["read_radius"] = ha0["read_radius"]
-    halos_np["search_radius"] = ha0["search_radius"]
-
     for _ in range(args.warmup):
-        step()
-    ms_halo, ms_mesh, ms_reorder = [], [], []
+        one_pass(False)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        raw, nleft = step()
-        ms_halo.append(engine.kernel_ms("halo"))
-        ms_mesh.append(engine.kernel_ms("mesh"))
-        ms_reorder.append(engine.kernel_ms("reorder"))
+        for _ in range(args.passes_per_step):
+            one_pass(True)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    npasses = args.steps * args.passes_per_step
 
+    raw = state["raw"]
     stats = raw["stats"]
     ok = raw["status"] == 0
     n_sel = int(stats[ok, 1].sum())
     n_cand = int(stats[ok, 2].sum())
     evals = n_sel * A
-    tot = torch.tensor([evals, int(ok.sum()), n_cand], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tot = torch.tensor([evals, int(ok.sum()), n_cand, n_region, state["nleft"]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    evals_all, halos_all, ncand_all = (float(x) for x in tot.tolist())
+    evals_all, halos_all_ok, ncand_all, nregion_all, nleft_all = (float(x) for x in tot.tolist())
+    cat_table = state["catalogue"][0]
+    assert cat_table.shape[0] == wl["n_halo"], (cat_table.shape, wl["n_halo"])
 
     if rank == 0:
         ncols = engine.row_columns
@@ -268,31 +385,40 @@ def main():
         # HBM-side bytes of the halo kernels from the committed PMC passes (rocprofv3 cannot run inside the
         # bench): only quoted when the workload is the one that was profiled
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "round1", "final_c3_hbm_traffic.json")) as f:
-                pj = json.load(f)
-            if pj.get("workload") == wl["name"] and pj.get("seed") == args.seed and world == 1:
-                traffic = pj["traffic_bytes_per_step_corrected"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        tnote = "no PMC profile of this workload committed"
+        for prof in ("round2", "round1"):
+            try:
+                with open(os.path.join(ROOT, "profiles", prof, "final_c3_hbm_traffic.json")) as f:
+                    pj = json.load(f)
+                if pj.get("workload_key", "c3") == args.workload and pj.get("seed") == args.seed and world == 1:
+                    traffic = pj["traffic_bytes_per_step_corrected"]
+                    tnote = f"2*FETCH_SIZE + WRITE_SIZE of the halo kernels from profiles/{prof}/final_c3_hbm_traffic.json (separate --pmc passes, gfx950 read correction)"
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
+        b_reorder = wl["n_part"] * 60 if world == 1 else n_region * 60   # 24 B read + (24 + 4) B written + cell/rank traffic 8 B
         line = {
             "metric": "particle_aperture_evals_per_s",
-            "value": evals_all * args.steps / dt,
+            "value": evals_all * npasses / dt,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "particles_per_gpu": wl["n_part"],
-                       "halos_per_gpu": H, "calculations": A, "seed": args.seed,
-                       "mesh_resolution": int(halo_tasks.mesh_resolution(wl["n_part"]))},
-            "halos_per_s": halos_all * args.steps / dt,
-            "halos_unfinished": int(nleft), "catalogue_radius_updates": n_radius_updates,
+            "config": {"workload": wl["name"], "workload_key": args.workload, "particles": wl["n_part"],
+                       "halos": wl["n_halo"], "calculations": A, "seed": args.seed,
+                       "passes_per_step": args.passes_per_step,
+                       "chunks": world, "mesh_resolution": int(halo_tasks.mesh_resolution(n_region))},
+            "ms_per_pass": dt / npasses * 1e3,
+            "halos_per_s": halos_all_ok * npasses / dt,
+            "halos_unfinished": int(nleft_all),
+            "process_halos_calls_per_pass": raw["iterations"], "catalogue_radius_updates": raw["radius_updates"],
+            "replication": nregion_all / n_box,
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
                           "reorder": float(np.mean(ms_reorder)),
                           "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),
@@ -303,16 +429,16 @@ def main():
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes": b_alg,
-                "note": "sum_h n_cand(h)*68 B + H*P*8 B per step / HIP-event duration of the three concurrent k_halo "
-                        "launches (g64/g256/g1024); traffic = 2*FETCH_SIZE + WRITE_SIZE of those launches from "
-                        "profiles/round1/final_c3_hbm_traffic.json (separate --pmc passes, gfx950 read correction)",
+                "note": "rank 0, per pass: sum_h n_cand(h)*68 B + H*P*8 B / HIP-event duration of the halo kernels of all "
+                        "process_halos calls of the pass (concurrent class launches, events on the engine's streams); traffic: " + tnote,
             },
             "reorder_roofline": {
-                "achieved": 2 * wl["n_part"] * B_PARTICLE / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,
-                "unit": "GB/s", "algorithmic_bytes": 2 * wl["n_part"] * B_PARTICLE,
+                "achieved": b_reorder / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,
+                "unit": "GB/s", "algorithmic_bytes": b_reorder,
+                "note": "bytes the placement pass moves: coordinates read (24 B) and written in cell order (24 B), "
+                        "permutation (4 B), cell id + rank read back (8 B); velocities / masses / ids are not moved",
             },
             "generation_s": t_gen,
-            "phase_cycles": engine.phase_cycles(),
             "n_loop_mean": float(stats[ok, 0].mean()), "n_sel_max": int(stats[ok, 1].max()),
             "n_sel_sum": n_sel, "n_cand_sum": n_cand,
         }  # fmt: skip

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SOAP_ENGINE_ABI_VERSION 2
+#define SOAP_ENGINE_ABI_VERSION 3
 
 /* particle types the selections know about, in the reference's concatenation order
  * (SO_properties.py:3520-3550).  "slot" below is the position in this list. */
@@ -105,8 +105,13 @@ enum {
     SOAP_CALC_FLAG_INERTIA = 4,    /* bound subhalo / SO: the eight inertia tensors of the total and the dark
                                       matter mass are wanted (inertia_tensors.py:19-132): up to 20 passes per
                                       tensor family over the particles of the search sphere */
-    SOAP_CALC_FLAG_ROTATION = 2    /* gas / star / baryon kappa_corot and disc-to-total fractions are wanted
+    SOAP_CALC_FLAG_ROTATION = 2,   /* gas / star / baryon kappa_corot and disc-to-total fractions are wanted
                                       (kinematic_properties.py:266-425): one more pass over the selection */
+    SOAP_CALC_FLAG_STRICT_COPY = 8 /* parameters.strict_halo_copy(): an aperture that repeats the next-smaller one
+                                      (EncloseRadius rule) leaves the properties that depend on the aperture size
+                                      itself at zero instead of copying them (aperture_properties.py:4117-4120,
+                                      projected_aperture_properties.py:1880-1883).  Of the properties this engine
+                                      emits those are the iterative 2D inertia tensors of projected apertures */
 };
 
 /* per-halo status column */
@@ -175,6 +180,29 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n_halo, const double *co
                                 const double *search_radius, const double *read_radius,
                                 const int64_t *index, const int32_t *is_central,
                                 const int64_t *nr_bound_part);
+
+/*
+ * Optional, after soap_engine_stage_halos: how far around each halo centre the STAGED particles are complete
+ * (resident_radius[i] >= read_radius[i]; host pointer, n_halo doubles; NULL = read_radius, the reference's
+ * contract).  A halo whose calculations ask for more than its read radius is then not handed back with
+ * SOAP_HALO_NEED_LARGER_READ_RADIUS as long as the enlarged read radius max(1.5 read_radius, search_radius)
+ * (halo_tasks.py:393-402) stays within resident_radius: the engine applies the update itself and starts the
+ * halo again from the new search radius, exactly what the next process_halos call of ChunkTask's loop
+ * (chunk_tasks.py:189-367) would do with a re-read region -- without the re-read.  The radii fetched
+ * afterwards are the updated ones.
+ */
+int32_t soap_engine_set_resident_radius(soap_engine *h, const double *resident_radius);
+
+/*
+ * Verification probe, before soap_engine_run: record which particles calculation `calc` of halo row `row`
+ * USES -- the prefix of the halo's radially sorted slab the property passes sum over (bound particles only
+ * for the bound subhalo and exclusive spheres).  After the run soap_engine_fetch_members returns how many
+ * were recorded (<0 on error, 0 if the calculation was filtered / copied / zero) and writes up to `cap`
+ * pairs (type_slot, index in the staged arrays of that type), sorted by (type_slot, index).
+ * row < 0 switches the probe off.  Projected apertures are not supported (their members are chosen per axis).
+ */
+int32_t soap_engine_set_member_probe(soap_engine *h, int64_t row, int32_t calc, int64_t cap);
+int64_t soap_engine_fetch_members(soap_engine *h, int32_t *type_slot, int64_t *index, int64_t cap);
 
 /*
  * process_halos(): run every calculation of `calcs` for every staged halo.

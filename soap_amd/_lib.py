@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsoap_engine.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NTYPES = 4
 
 
@@ -73,6 +73,9 @@ SYMBOLS = {
         [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p],
     ),  # fmt: skip
+    "soap_engine_set_resident_radius": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "soap_engine_set_member_probe": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
+    "soap_engine_fetch_members": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "soap_engine_run": (C.c_int32, [C.c_void_p, C.POINTER(CalcDesc), C.c_int32, C.c_double]),
     "soap_engine_row_columns": (C.c_int64, [C.c_void_p]),
     "soap_engine_fetch": (

@@ -31,6 +31,30 @@ def spatial_sort_order(halo_cofp: np.ndarray, halo_index: np.ndarray, cell_size,
     return np.lexsort((np.asarray(halo_index, dtype=np.int64), cell_index))
 
 
+def _floor_divide(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """NumPy's `a // b` for doubles (npy_divmod: fmod, then a correction), on the device, so that the cell of a
+    halo centre is the one `spatial_sort_order` finds on the host."""
+    mod = torch.fmod(a, b)
+    div = (a - mod) / b
+    adjust = (mod != 0) & ((b < 0) != (mod < 0))
+    div = torch.where(adjust, div - 1.0, div)
+    floordiv = torch.floor(div)
+    floordiv = torch.where(div - floordiv > 0.5, floordiv + 1.0, floordiv)
+    return torch.where(div != 0, floordiv, torch.zeros_like(div))
+
+
+def spatial_sort_order_device(cofp: torch.Tensor, index: torch.Tensor, cell_size, dimension) -> torch.Tensor:
+    """`spatial_sort_order` with the halo table resident on the device: two stable sorts (catalogue index,
+    then cell index) give the (cell, index) order of combine_chunks.py:38-52."""
+    assert dimension[0] >= dimension[1] >= dimension[2]
+    cs = torch.as_tensor(np.broadcast_to(np.asarray(cell_size, dtype=np.float64), (3,)).copy(), device=cofp.device)
+    ci = _floor_divide(cofp, cs[None, :].expand_as(cofp)).to(torch.int64)
+    cell_index = ci[:, 0] * dimension[0] ** 2 + ci[:, 1] * dimension[1] + ci[:, 2]
+    o1 = torch.argsort(index, stable=True)
+    o2 = torch.argsort(cell_index[o1], stable=True)
+    return o1[o2]
+
+
 def gather_catalogue(table: torch.Tensor, cofp: torch.Tensor, index: torch.Tensor, cell_size,
                      dimension, group=None):  # fmt: skip
     """
@@ -38,18 +62,26 @@ def gather_catalogue(table: torch.Tensor, cofp: torch.Tensor, index: torch.Tenso
     this rank's device.  Ranks may hold different numbers of halos: rows are padded to the
     maximum for the (single) all-gather and the padding is dropped afterwards.
     Returns (table_all, cofp_all, index_all) in final-catalogue order, identical on all ranks.
+    The ordering runs where the table lives: on the GPU for CUDA tensors (nothing but the row
+    counts crosses to the host), with NumPy for the gloo / CPU tests.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n_local, ncols = table.shape
     dev = table.device
+
+    def order_of(c, i):
+        if c.is_cuda:
+            return spatial_sort_order_device(c, i, cell_size, dimension)
+        return torch.as_tensor(spatial_sort_order(c.numpy(), i.numpy(), cell_size, dimension))
+
     if world == 1:
-        order = spatial_sort_order(cofp.cpu().numpy(), index.cpu().numpy(), cell_size, dimension)
-        o = torch.as_tensor(order, device=dev)
+        o = order_of(cofp, index)
         return table[o], cofp[o], index[o]
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, mine, group=group)
-    nmax = int(counts.max().item())
+    counts_h = counts.tolist()
+    nmax = max(counts_h)
     # one payload row per halo: [catalogue index bits | cofp(3) | table row], padded to nmax rows
     payload = torch.zeros((nmax, ncols + 4), dtype=torch.float64, device=dev)
     payload[:n_local, 0] = index.to(torch.int64).view(torch.float64) if index.dtype == torch.int64 else index
@@ -57,12 +89,12 @@ def gather_catalogue(table: torch.Tensor, cofp: torch.Tensor, index: torch.Tenso
     payload[:n_local, 4:] = table
     gathered = torch.empty((world * nmax, ncols + 4), dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(gathered, payload, group=group)
-    keep = torch.cat([torch.arange(int(c), device=dev) + r * nmax for r, c in enumerate(counts.tolist())])
-    gathered = gathered[keep]
+    if min(counts_h) != nmax:
+        keep = torch.cat([torch.arange(int(c), device=dev) + r * nmax for r, c in enumerate(counts_h)])
+        gathered = gathered[keep]
     index_all = gathered[:, 0].contiguous().view(torch.int64)
-    cofp_all = gathered[:, 1:4]
-    order = spatial_sort_order(cofp_all.cpu().numpy(), index_all.cpu().numpy(), cell_size, dimension)
-    o = torch.as_tensor(order, device=dev)
+    cofp_all = gathered[:, 1:4].contiguous()
+    o = order_of(cofp_all, index_all)
     return gathered[o, 4:], cofp_all[o], index_all[o]
 
 

@@ -72,6 +72,47 @@ def mask_cells(cell_size, dimension, centre, radius, done) -> np.ndarray:
     return (hit > 0).reshape(dimension)
 
 
+def resident_radius(mask: np.ndarray, cell_size, centre, read_radius, factor: float = 1.5, steps: int = 8) -> np.ndarray:
+    """
+    How far around each halo centre the cells of `mask` are complete: the largest of read_radius * factor^k
+    (k = 0 .. steps) whose box -- with the half-cell margin of mask_cells.py:30-34 -- lies inside flagged cells.
+    The engine may then apply read-radius updates (halo_tasks.py:393-402) that stay within it without a re-read
+    (soap_engine_set_resident_radius).  A fully flagged periodic box is complete to any radius.
+    """
+    mask = np.asarray(mask, dtype=bool)
+    centre = np.asarray(centre, dtype=np.float64).reshape(-1, 3)
+    rr = np.asarray(read_radius, dtype=np.float64)
+    if mask.all():
+        return np.full(rr.shape, np.inf)
+    dim = np.array(mask.shape)
+    cs = np.broadcast_to(np.asarray(cell_size, dtype=np.float64), (3,))
+    # number of cells NOT flagged in any box of the 3x tiled grid, from a summed-volume table
+    miss = np.tile(~mask, (3, 3, 3)).astype(np.int64)
+    sv = np.zeros(tuple(3 * dim + 1), dtype=np.int64)
+    sv[1:, 1:, 1:] = miss.cumsum(0).cumsum(1).cumsum(2)
+
+    def missing(lo, hi):   # inclusive index boxes in the tiled grid
+        x0, y0, z0 = lo[:, 0], lo[:, 1], lo[:, 2]
+        x1, y1, z1 = hi[:, 0] + 1, hi[:, 1] + 1, hi[:, 2] + 1
+        return (sv[x1, y1, z1] - sv[x0, y1, z1] - sv[x1, y0, z1] - sv[x1, y1, z0]
+                + sv[x0, y0, z1] + sv[x0, y1, z0] + sv[x1, y0, z0] - sv[x0, y0, z0])  # fmt: skip
+
+    out = rr.copy()
+    alive = np.ones(rr.shape, dtype=bool)
+    r = rr.copy()
+    for k in range(steps + 1):
+        imin = np.floor((centre - r[:, None] - 0.5 * cs[None, :]) / cs[None, :]).astype(np.int64)
+        imax = np.floor((centre + r[:, None] + 0.5 * cs[None, :]) / cs[None, :]).astype(np.int64)
+        fits = np.all(imax - imin + 1 <= dim[None, :], axis=1) & np.all(imin >= -dim[None, :], axis=1) & np.all(imax < 2 * dim[None, :], axis=1)
+        lo = np.where(fits[:, None], imin + dim[None, :], 0)
+        hi = np.where(fits[:, None], imax + dim[None, :], 0)
+        covered = fits & (missing(lo, hi) == 0)
+        alive &= covered
+        out = np.where(alive, r, out)
+        r = r * factor
+    return out
+
+
 class SnapshotCells:
     """
     Particle arrays in top-level-cell order, the in-memory stand-in of a SWIFT snapshot
@@ -179,8 +220,8 @@ def chunk_ref_pos(centre) -> np.ndarray:
     return (np.amin(centre, axis=0) + np.amax(centre, axis=0)) / 2
 
 
-def read_chunk(snapshot: SnapshotCells, halo_arrays: Dict, wrap: bool = True):
-    """Mask + read (+ box wrap) for the unfinished halos of `halo_arrays`.  Returns (data, nr_cells)."""
+def read_chunk(snapshot: SnapshotCells, halo_arrays: Dict, wrap: bool = True, return_mask: bool = False):
+    """Mask + read (+ box wrap) for the unfinished halos of `halo_arrays`.  Returns (data, nr_cells[, mask])."""
     done = halo_arrays.get("done")
     if done is None:
         done = np.zeros(len(halo_arrays["index"]), dtype=np.int32)
@@ -189,13 +230,15 @@ def read_chunk(snapshot: SnapshotCells, halo_arrays: Dict, wrap: bool = True):
     if wrap and not bool(mask.all()):
         ref = chunk_ref_pos(np.asarray(halo_arrays["cofp"]))
         data = {pt: dict(d, Coordinates=box_wrap(d["Coordinates"], ref, snapshot.boxsize)) for pt, d in data.items()}
+    if return_mask:
+        return data, int(mask.sum()), mask
     return data, int(mask.sum())
 
 
 def run_chunk_task(engine, snapshot: SnapshotCells, halo_prop_list: List, cellgrid, halo_arrays: Dict,
                    wrap: bool = True, max_iterations: int = 12, results: Optional[ResultSet] = None,
                    log: Optional[List] = None, data: Optional[Dict] = None,
-                   raw_tables: Optional[List] = None) -> ResultSet:  # fmt: skip
+                   raw_tables: Optional[List] = None, use_resident_radius: bool = False) -> ResultSet:  # fmt: skip
     """
     Process every halo of one chunk (chunk_tasks.py:189-367).  `halo_arrays` holds the chunk's halo rows
     (index, cofp, search_radius, read_radius, is_central, nr_bound_part), already in processing order
@@ -203,6 +246,8 @@ def run_chunk_task(engine, snapshot: SnapshotCells, halo_prop_list: List, cellgr
     cells the unfinished halos need with their current read radius, stages them (one mesh per particle
     type) and runs `process_halos`; halos that come back with a larger read radius (halo_tasks.py:393-402)
     go round again.  `data` short-cuts the first read (the region is already resident).
+    `use_resident_radius=True` tells the engine how far the cells that were read are complete around every halo
+    (`resident_radius`), so that read-radius updates inside the region need no further iteration.
     `raw_tables` collects, per iteration, the engine's fp64 rows of the finished halos with their
     catalogue columns and statistics (what the catalogue gather of SURVEY.md 8(e) concatenates).
     `wrap=False` leaves the coordinates as stored: the engine enumerates the periodic copies of a search
@@ -214,15 +259,19 @@ def run_chunk_task(engine, snapshot: SnapshotCells, halo_prop_list: List, cellgr
     for it in range(max_iterations):
         if not np.any(halo_arrays["done"] == 0):
             break
+        resident = None
         if data is None:
-            data, nr_cells = read_chunk(snapshot, halo_arrays, wrap)
+            data, nr_cells, mask = read_chunk(snapshot, halo_arrays, wrap, return_mask=True)
+            if use_resident_radius:
+                resident = resident_radius(mask, snapshot.cell_size, halo_arrays["cofp"], halo_arrays["read_radius"])
         else:
             nr_cells = -1
         nr_parts = sum(int(d["Coordinates"].shape[0]) for d in data.values())
         if nr_parts == 0:
             raise RuntimeError("Task has zero particles?!")   # chunk_tasks.py:262-264
         halo_tasks.stage_chunk(engine, data)
-        out = halo_tasks.process_halos(engine, halo_prop_list, cellgrid, halo_arrays, None, unpack=False)
+        out = halo_tasks.process_halos(engine, halo_prop_list, cellgrid, halo_arrays, None, unpack=False,
+                                       resident_radius=resident)
         raw = out[4]
         ok = raw["status"] == halo_tasks.STATUS_OK
         rows = raw["rows"][ok]

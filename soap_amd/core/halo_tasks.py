@@ -136,7 +136,7 @@ def bind_results(engine: Engine, halo_prop_list: List, raw: Dict, halo_arrays: D
 
 
 def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, results,
-                  unpack: bool = True):  # fmt: skip
+                  unpack: bool = True, resident_radius=None):  # fmt: skip
     """
     Compute every calculation of `halo_prop_list` for every halo of `halo_arrays` with
     done == 0.  halo_arrays: dict of NumPy arrays index, cofp, search_radius, read_radius,
@@ -144,6 +144,11 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     done=1 and one `halo_result` dict appended to `results` (anything with .append);
     halos that need a larger region get their read_radius/search_radius updated exactly as
     the reference does (halo_tasks.py:393-402) and stay at done=0.
+
+    `resident_radius` (scalar or per halo of halo_arrays; not in the reference): radius about each centre inside
+    which the staged particles are known to be complete.  Read-radius updates that stay inside it are applied by
+    the engine itself, which then starts the halo again as the next call would (halo_tasks.py:393-402 +
+    chunk_tasks.py:189-367) -- the halo comes back finished, with the updated radii, instead of not done.
 
     Returns (total_time, task_time, nr_halos_left, nr_done, raw) where raw holds the
     engine's table/status/stats for callers that do not want per-halo dictionaries.
@@ -154,10 +159,14 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     target_density = target_density_of(halo_prop_list, cellgrid)
     # first pass over a chunk: every halo is still to do, the catalogue arrays go in as they are
     pick = (lambda a: np.asarray(a)) if todo.size == len(halo_arrays["done"]) else (lambda a: np.asarray(a)[todo])
+    if resident_radius is not None:
+        resident_radius = np.broadcast_to(np.asarray(resident_radius, dtype=np.float64), (len(halo_arrays["done"]),))
+        resident_radius = np.maximum(pick(resident_radius), pick(halo_arrays["read_radius"]))
     engine.stage_halos(
         pick(halo_arrays["cofp"]), pick(halo_arrays["search_radius"]),
         pick(halo_arrays["read_radius"]), pick(halo_arrays["index"]),
         pick(halo_arrays["is_central"]), pick(halo_arrays["nr_bound_part"]),
+        resident_radius=resident_radius,
     )  # fmt: skip
     t0_task = time.time()
     engine.run(calcs, target_density)
@@ -176,8 +185,9 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     ok = status == STATUS_OK
     again = status == STATUS_NEED_LARGER_READ_RADIUS
     halo_arrays["done"][todo[ok]] = 1
-    halo_arrays["read_radius"][todo[again]] = out["read_radius"][again]
-    halo_arrays["search_radius"][todo[again]] = out["search_radius"][again]
+    upd = again | ok   # finished halos carry the radii of their in-engine retries (resident_radius), if any
+    halo_arrays["read_radius"][todo[upd]] = out["read_radius"][upd]
+    halo_arrays["search_radius"][todo[upd]] = out["search_radius"][upd]
 
     if unpack:
         coloff = np.concatenate([[0], np.cumsum([engine.desc_columns(c) for c in calcs])])

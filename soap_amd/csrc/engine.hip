@@ -104,6 +104,7 @@ struct HaloDev {
     long long *stats;  // [n][4]
     const int *todo;   // optional list of rows to process (retry pass), or null
     long long n_todo;
+    const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
 };
 
 struct RunParams {
@@ -126,6 +127,12 @@ struct RunParams {
     unsigned long long *phase;   // [32] accumulated s_memtime cycles of thread 0 per phase
     const soap_calc_desc *calcs;  // device copy
     const int *coloff;            // device: column offset per calc
+    // member probe (soap_engine_set_member_probe): halo row / calculation to record, packed (type slot << 56 | original index)
+    long long probe_row;
+    int probe_calc;
+    long long probe_cap;
+    unsigned long long *probe_out;
+    unsigned *probe_count;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -809,16 +816,45 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
 // ------------------------------------------------------------------------------------------
 // Size-keyed cache of device allocations: hipMalloc/hipFree of multi-GB buffers cost milliseconds
 // each and would dominate a staging call that is repeated for every chunk.
+// Chunks differ in size, so blocks of a previous chunk rarely fit the next one exactly: a request takes the
+// smallest cached block that is large enough but at most 25 % larger (best fit), the cache is trimmed to
+// `max_cached` bytes whenever a block comes back (largest first: those are the ones a differently sized chunk
+// cannot reuse), and a failed hipMalloc empties the cache and tries once more.
 struct DevPool {
-    std::multimap<size_t, void *> free_blocks;
+    std::multimap<size_t, void *> free_blocks;   // capacity -> block
+    std::map<void *, size_t> capacity;           // blocks handed out: their real size
+    size_t cached = 0, max_cached = (size_t)8 << 30;
     hipError_t alloc(void **p, size_t bytes) {
         if (bytes == 0) bytes = 8;
-        auto it = free_blocks.find(bytes);
-        if (it != free_blocks.end()) { *p = it->second; free_blocks.erase(it); return hipSuccess; }
-        return hipMalloc(p, bytes);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4) {
+            *p = it->second; capacity[*p] = it->first; cached -= it->first; free_blocks.erase(it);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            purge();
+            e = hipMalloc(p, bytes);
+        }
+        if (e == hipSuccess) capacity[*p] = bytes;
+        return e;
     }
-    void release(void *p, size_t bytes) { if (p) free_blocks.emplace(bytes == 0 ? 8 : bytes, p); }
-    void purge() { for (auto &kv : free_blocks) (void)hipFree(kv.second); free_blocks.clear(); }
+    void release(void *p, size_t bytes) {
+        if (!p) return;
+        auto it = capacity.find(p);
+        const size_t cap = it != capacity.end() ? it->second : (bytes == 0 ? 8 : bytes);
+        if (it != capacity.end()) capacity.erase(it);
+        free_blocks.emplace(cap, p);
+        cached += cap;
+        while (cached > max_cached && !free_blocks.empty()) {
+            auto big = std::prev(free_blocks.end());
+            (void)hipFree(big->second);
+            cached -= big->first;
+            free_blocks.erase(big);
+        }
+    }
+    void purge() { for (auto &kv : free_blocks) (void)hipFree(kv.second); free_blocks.clear(); cached = 0; }
 };
 
 struct TypeHost {
@@ -854,6 +890,12 @@ struct soap_engine {
     double *d_cofp = nullptr, *d_search = nullptr, *d_read = nullptr;
     long long *d_index = nullptr, *d_nrbound = nullptr, *d_stats = nullptr;
     int *d_central = nullptr, *d_status = nullptr, *d_todo = nullptr;
+    double *d_resident = nullptr;
+    // member probe
+    long long probe_row = -1, probe_cap = 0;
+    int probe_calc = 0;
+    unsigned long long *d_probe = nullptr;
+    unsigned *d_probe_count = nullptr;
     // run
     long long ncols = 0;
     double *d_table = nullptr;
@@ -913,6 +955,8 @@ static void free_slabs(soap_engine *h) {
     for (int k = 0; k < 3; k++) free_slab(h->cls[k]);
 }
 
+static int32_t create_resources(soap_engine *h);
+
 extern "C" {
 
 int32_t soap_engine_abi_version(void) { return SOAP_ENGINE_ABI_VERSION; }
@@ -953,6 +997,13 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
     HIPCHECK(hipSetDevice(cfg->device));
     soap_engine *h = new soap_engine();
     h->cfg = *cfg;
+    const int32_t rc = create_resources(h);
+    if (rc != 0) { const std::string msg = g_err; (void)soap_engine_destroy(h); g_err = msg; return rc; }
+    *out = h;
+    return 0;
+}
+
+static int32_t create_resources(soap_engine *h) {
     HIPCHECK(hipStreamCreate(&h->stream));
     HIPCHECK(hipEventCreate(&h->ev0));
     HIPCHECK(hipEventCreate(&h->ev1));
@@ -976,7 +1027,6 @@ int32_t soap_engine_create(const soap_engine_config *cfg, soap_engine **out) {
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
-    *out = h;
     return 0;
 }
 
@@ -986,9 +1036,10 @@ static void free_halos(soap_engine *h) {
     const size_t n = (size_t)h->n_halo;
     std::pair<void *, size_t> ptrs[] = {{h->d_cofp, n * 24}, {h->d_search, n * 8}, {h->d_read, n * 8}, {h->d_index, n * 8},
                                         {h->d_nrbound, n * 8}, {h->d_stats, n * 32}, {h->d_central, n * 4},
-                                        {h->d_status, n * 4}, {h->d_todo, n * 4}};
+                                        {h->d_status, n * 4}, {h->d_todo, n * 4}, {h->d_resident, n * 8}};
     for (auto &p : ptrs) if (p.first) h->pool.release(p.first, p.second);
     h->d_cofp = h->d_search = h->d_read = nullptr;
+    h->d_resident = nullptr;
     h->d_index = h->d_nrbound = h->d_stats = nullptr;
     h->d_central = h->d_status = h->d_todo = nullptr;
     h->n_halo = 0;
@@ -1015,6 +1066,8 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_phase) (void)hipFree(h->d_phase);
+    if (h->d_probe) (void)hipFree(h->d_probe);
+    if (h->d_probe_count) (void)hipFree(h->d_probe_count);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1058,120 +1111,133 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     if (grnr_bytes != 4 && grnr_bytes != 8) return fail(-4, "grnr_bytes must be 4 or 8");
     if (resolution < 1 || resolution > 256) return fail(-5, "mesh resolution must be in [1,256]");
     HIPCHECK(hipSetDevice(h->cfg.device));
-    TypeHost &T = h->t[ts];
     DevPool &pool = h->pool;
-    T.release(pool);
+    h->t[ts].release(pool);
     if (n == 0) return 0;   // SharedMesh.empty (shared_mesh.py:25-27)
     if (!pos || !vel || !mass) return fail(-6, "null particle array");
     hipStream_t st = h->stream;
-    const double *dpos = pos, *dvel = vel, *dmass = mass;
-    const void *dgr = grnr;
-    const long long *dfof = (const long long *)fof;
-    std::vector<std::pair<void *, size_t>> tmp;
-    if (!on_device) {
-        const size_t vbytes = (size_t)n * (nu ? 8 : 24);   // neutrinos: one weight per particle in place of a velocity
-        void *a, *b, *c, *d = nullptr, *e = nullptr;
-        HIPCHECK(pool.alloc(&a, (size_t)n * 24)); tmp.push_back({a, (size_t)n * 24});
-        HIPCHECK(pool.alloc(&b, vbytes)); tmp.push_back({b, vbytes});
-        HIPCHECK(pool.alloc(&c, (size_t)n * 8)); tmp.push_back({c, (size_t)n * 8});
-        HIPCHECK(hipMemcpyAsync(a, pos, (size_t)n * 24, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(b, vel, vbytes, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        if (!nu) {
-            HIPCHECK(pool.alloc(&d, (size_t)n * grnr_bytes)); tmp.push_back({d, (size_t)n * grnr_bytes});
-            HIPCHECK(pool.alloc(&e, (size_t)n * 8)); tmp.push_back({e, (size_t)n * 8});
-            HIPCHECK(hipMemcpyAsync(d, grnr, (size_t)n * grnr_bytes, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(e, fof, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        }
-        dpos = (const double *)a; dvel = (const double *)b; dmass = (const double *)c;
-        dgr = d; dfof = (const long long *)e;
-    }
-    auto cleanup = [&]() { for (auto &p : tmp) pool.release(p.first, p.second); tmp.clear(); };
-    auto keep_payload = [&]() {   // the coordinate copy goes back to the cache, the rest lives as long as the mesh
-        if (tmp.empty()) return;
-        pool.release(tmp[0].first, tmp[0].second);
-        for (size_t k = 1; k < tmp.size(); k++) T.owned.push_back(tmp[k]);
-        tmp.clear();
+    // The new mesh is built in a local object and installed only when every step succeeded: a failed allocation
+    // or kernel leaves the slot empty (n == 0), never half-built, and everything allocated on the way goes back
+    // to the cache.
+    TypeHost T;
+    std::vector<std::pair<void *, size_t>> inputs;    // device copies of host inputs
+    std::vector<std::pair<void *, size_t>> scratch;   // temporaries of the mesh build
+    hipEvent_t ev2 = nullptr;
+    auto grab = [&](void **p, size_t bytes, std::vector<std::pair<void *, size_t>> &owner) -> hipError_t {
+        hipError_t e = pool.alloc(p, bytes);
+        if (e == hipSuccess) owner.push_back({*p, bytes});
+        return e;
     };
-
-    HIPCHECK(hipEventRecord(h->ev0, st));
-    // bounding box (shared_mesh.py:33-61)
-    const int gmm = 1024;
-    double *d_partial;
-    HIPCHECK(pool.alloc((void **)&d_partial, gmm * 6 * sizeof(double)));
-    hipLaunchKernelGGL(k_minmax, dim3(gmm), dim3(BLK), 0, st, dpos, (long long)n, d_partial);
-    std::vector<double> part(gmm * 6);
-    HIPCHECK(hipMemcpyAsync(part.data(), d_partial, gmm * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipStreamSynchronize(st));
-    pool.release(d_partial, gmm * 6 * sizeof(double));
-    for (int d = 0; d < 3; d++) { T.pos_min[d] = INFINITY; T.pos_max[d] = -INFINITY; }
-    for (int b = 0; b < gmm; b++)
-        for (int d = 0; d < 3; d++) {
-            T.pos_min[d] = std::min(T.pos_min[d], part[b * 6 + d]);
-            T.pos_max[d] = std::max(T.pos_max[d], part[b * 6 + 3 + d]);
+    auto body = [&]() -> int32_t {
+        const double *dpos = pos, *dvel = vel, *dmass = mass;
+        const void *dgr = grnr;
+        const long long *dfof = (const long long *)fof;
+        if (!on_device) {
+            const size_t vbytes = (size_t)n * (nu ? 8 : 24);   // neutrinos: one weight per particle in place of a velocity
+            void *a, *b, *c, *d = nullptr, *e = nullptr;
+            HIPCHECK(grab(&a, (size_t)n * 24, inputs));
+            HIPCHECK(grab(&b, vbytes, inputs));
+            HIPCHECK(grab(&c, (size_t)n * 8, inputs));
+            HIPCHECK(hipMemcpyAsync(a, pos, (size_t)n * 24, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(b, vel, vbytes, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * 8, hipMemcpyHostToDevice, st));
+            if (!nu) {
+                HIPCHECK(grab(&d, (size_t)n * grnr_bytes, inputs));
+                HIPCHECK(grab(&e, (size_t)n * 8, inputs));
+                HIPCHECK(hipMemcpyAsync(d, grnr, (size_t)n * grnr_bytes, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipMemcpyAsync(e, fof, (size_t)n * 8, hipMemcpyHostToDevice, st));
+            }
+            dpos = (const double *)a; dvel = (const double *)b; dmass = (const double *)c;
+            dgr = d; dfof = (const long long *)e;
         }
-    for (int d = 0; d < 3; d++) {
-        if (!(T.pos_min[d] <= T.pos_max[d])) { cleanup(); return fail(-7, "non-finite coordinates"); }
-        if (T.pos_min[d] == T.pos_max[d]) T.pos_max[d] = T.pos_min[d] + 1.0;
-        T.cell_size[d] = (T.pos_max[d] - T.pos_min[d]) / (double)resolution;
-    }
-    T.res = resolution;
-    T.n = n;
-    T.grnr64 = grnr_bytes == 8;
-    const long long ncell = (long long)resolution * resolution * resolution;
+        HIPCHECK(hipEventRecord(h->ev0, st));
+        // bounding box (shared_mesh.py:33-61)
+        const int gmm = 1024;
+        double *d_partial;
+        HIPCHECK(grab((void **)&d_partial, gmm * 6 * sizeof(double), scratch));
+        hipLaunchKernelGGL(k_minmax, dim3(gmm), dim3(BLK), 0, st, dpos, (long long)n, d_partial);
+        std::vector<double> part(gmm * 6);
+        HIPCHECK(hipMemcpyAsync(part.data(), d_partial, gmm * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        for (int d = 0; d < 3; d++) { T.pos_min[d] = INFINITY; T.pos_max[d] = -INFINITY; }
+        for (int b = 0; b < gmm; b++)
+            for (int d = 0; d < 3; d++) {
+                T.pos_min[d] = std::min(T.pos_min[d], part[b * 6 + d]);
+                T.pos_max[d] = std::max(T.pos_max[d], part[b * 6 + 3 + d]);
+            }
+        for (int d = 0; d < 3; d++) {
+            if (!(T.pos_min[d] <= T.pos_max[d])) return fail(-7, "non-finite coordinates");
+            if (T.pos_min[d] == T.pos_max[d]) T.pos_max[d] = T.pos_min[d] + 1.0;
+            T.cell_size[d] = (T.pos_max[d] - T.pos_min[d]) / (double)resolution;
+        }
+        T.res = resolution;
+        T.n = n;
+        T.grnr64 = grnr_bytes == 8;
+        const long long ncell = (long long)resolution * resolution * resolution;
 
-    unsigned *d_cell, *d_count, *d_rank, *d_sortidx, *d_tilesum;
-    HIPCHECK(pool.alloc((void **)&d_cell, (size_t)n * 4));
-    HIPCHECK(pool.alloc((void **)&d_count, (size_t)ncell * 4));
-    HIPCHECK(pool.alloc((void **)&d_rank, (size_t)n * 4));
-    HIPCHECK(pool.alloc((void **)&d_sortidx, (size_t)n * 4));
-    HIPCHECK(pool.alloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
-    HIPCHECK(hipMemsetAsync(d_count, 0, (size_t)ncell * 4, st));
-    MeshGeom g;
-    for (int d = 0; d < 3; d++) { g.pos_min[d] = T.pos_min[d]; g.cell_size[d] = T.cell_size[d]; }
-    g.res = resolution;
-    int grid = (int)std::min<long long>((n + BLK - 1) / BLK, 256 * 8);
-    hipLaunchKernelGGL(k_cellid, dim3(grid), dim3(BLK), 0, st, dpos, (long long)n, g, d_cell, d_count, d_rank);
-    long long ntiles = (ncell + SCAN_TILE - 1) / SCAN_TILE;
-    HIPCHECK(pool.alloc((void **)&d_tilesum, (size_t)ntiles * 4));
-    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, d_count, ncell, T.cell_offset, d_tilesum);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.cell_offset, ncell, d_tilesum, (unsigned)n);
-    HIPCHECK(hipEventRecord(h->ev1, st));
+        unsigned *d_cell, *d_count, *d_rank, *d_tilesum;
+        HIPCHECK(grab((void **)&d_cell, (size_t)n * 4, scratch));
+        HIPCHECK(grab((void **)&d_count, (size_t)ncell * 4, scratch));
+        HIPCHECK(grab((void **)&d_rank, (size_t)n * 4, scratch));
+        HIPCHECK(pool.alloc((void **)&T.orig, (size_t)n * 4));
+        HIPCHECK(pool.alloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
+        HIPCHECK(hipMemsetAsync(d_count, 0, (size_t)ncell * 4, st));
+        MeshGeom g;
+        for (int d = 0; d < 3; d++) { g.pos_min[d] = T.pos_min[d]; g.cell_size[d] = T.cell_size[d]; }
+        g.res = resolution;
+        int grid = (int)std::min<long long>((n + BLK - 1) / BLK, 256 * 8);
+        hipLaunchKernelGGL(k_cellid, dim3(grid), dim3(BLK), 0, st, dpos, (long long)n, g, d_cell, d_count, d_rank);
+        long long ntiles = (ncell + SCAN_TILE - 1) / SCAN_TILE;
+        HIPCHECK(grab((void **)&d_tilesum, (size_t)ntiles * 4, scratch));
+        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, d_count, ncell, T.cell_offset, d_tilesum);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.cell_offset, ncell, d_tilesum, (unsigned)n);
+        HIPCHECK(hipEventRecord(h->ev1, st));
 
-    // placement + coordinates into cell order
-    double **dp[] = {&T.x, &T.y, &T.z};
-    for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
-    T.vel = dvel; T.mass = dmass; T.fof = dfof;
-    if (T.grnr64) T.g64 = (const long long *)dgr; else T.g32 = (const int *)dgr;
-    if (nu) {
-        // profile mass = mass * weight (owned array); the raw masses take the place of the velocities
-        double *meff;
-        HIPCHECK(pool.alloc((void **)&meff, (size_t)n * 8));
-        hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (long long)n, meff);
-        T.owned.push_back({meff, (size_t)n * 8});
-        T.vel = dmass;
-        T.mass = meff;
-        T.g32 = nullptr; T.g64 = nullptr; T.fof = nullptr;
+        // placement + coordinates into cell order
+        double **dp[] = {&T.x, &T.y, &T.z};
+        for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
+        T.vel = dvel; T.mass = dmass; T.fof = dfof;
+        if (T.grnr64) T.g64 = (const long long *)dgr; else T.g32 = (const int *)dgr;
+        if (nu) {
+            // profile mass = mass * weight (owned array); the raw masses take the place of the velocities
+            double *meff;
+            HIPCHECK(pool.alloc((void **)&meff, (size_t)n * 8));
+            T.owned.push_back({meff, (size_t)n * 8});
+            hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (long long)n, meff);
+            T.vel = dmass;
+            T.mass = meff;
+            T.g32 = nullptr; T.g64 = nullptr; T.fof = nullptr;
+        }
+        HIPCHECK(hipEventCreate(&ev2));
+        hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset, T.orig,
+                           dpos, T.x, T.y, T.z);
+        HIPCHECK(hipEventRecord(ev2, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(-101, std::string("mesh build: ") + hipGetErrorString(le));
+        float ms1 = 0, ms2 = 0;
+        (void)hipEventElapsedTime(&ms1, h->ev0, h->ev1);
+        (void)hipEventElapsedTime(&ms2, h->ev1, ev2);
+        h->ms_mesh = ms1;
+        h->ms_reorder = ms2;
+        return 0;
+    };
+    const int32_t rc = body();
+    if (ev2) (void)hipEventDestroy(ev2);
+    for (auto &p : scratch) pool.release(p.first, p.second);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(st);   // nothing may still be writing into what goes back to the cache
+        for (auto &p : inputs) pool.release(p.first, p.second);
+        T.release(pool);
+        return rc;
     }
-    hipEvent_t ev2;
-    HIPCHECK(hipEventCreate(&ev2));
-    hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset, d_sortidx,
-                       dpos, T.x, T.y, T.z);
-    HIPCHECK(hipEventRecord(ev2, st));
-    HIPCHECK(hipStreamSynchronize(st));
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { cleanup(); return fail(-101, std::string("mesh build: ") + hipGetErrorString(le)); }
-    float ms1 = 0, ms2 = 0;
-    (void)hipEventElapsedTime(&ms1, h->ev0, h->ev1);
-    (void)hipEventElapsedTime(&ms2, h->ev1, ev2);
-    (void)hipEventDestroy(ev2);
-    h->ms_mesh = ms1;
-    h->ms_reorder = ms2;
-    T.orig = d_sortidx;   // original index of the particle now at position p
-    pool.release(d_cell, (size_t)n * 4); pool.release(d_count, (size_t)ncell * 4);
-    pool.release(d_rank, (size_t)n * 4); pool.release(d_tilesum, (size_t)ntiles * 4);
-    keep_payload();
+    // the coordinate copy goes back to the cache, the other device copies live as long as the mesh
+    if (!inputs.empty()) {
+        pool.release(inputs[0].first, inputs[0].second);
+        for (size_t k = 1; k < inputs.size(); k++) T.owned.push_back(inputs[k]);
+    }
+    h->t[ts] = T;
     return 0;
 }
 
@@ -1214,12 +1280,60 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n, const double *cofp,
     return 0;
 }
 
+int32_t soap_engine_set_resident_radius(soap_engine *h, const double *resident_radius) {
+    if (!h) return fail(-1, "null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->n_halo;
+    if (h->d_resident) { h->pool.release(h->d_resident, n * 8); h->d_resident = nullptr; }
+    if (!resident_radius || n == 0) return 0;
+    HIPCHECK(h->pool.alloc((void **)&h->d_resident, n * 8));
+    HIPCHECK(hipMemcpyAsync(h->d_resident, resident_radius, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t soap_engine_set_member_probe(soap_engine *h, int64_t row, int32_t calc, int64_t cap) {
+    if (!h) return fail(-1, "null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    if (row < 0) { h->probe_row = -1; return 0; }
+    if (calc < 0 || cap < 1) return fail(-2, "member probe: bad calculation or capacity");
+    if (cap > h->probe_cap || !h->d_probe) {
+        if (h->d_probe) (void)hipFree(h->d_probe);
+        h->d_probe = nullptr;
+        HIPCHECK(hipMalloc((void **)&h->d_probe, (size_t)cap * 8));
+    }
+    if (!h->d_probe_count) HIPCHECK(hipMalloc((void **)&h->d_probe_count, sizeof(unsigned)));
+    HIPCHECK(hipMemset(h->d_probe_count, 0, sizeof(unsigned)));
+    h->probe_row = row; h->probe_calc = calc; h->probe_cap = cap;
+    return 0;
+}
+
+int64_t soap_engine_fetch_members(soap_engine *h, int32_t *type_slot, int64_t *index, int64_t cap) {
+    if (!h) return fail(-1, "null handle");
+    if (h->probe_row < 0 || !h->d_probe) return fail(-2, "no member probe set");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    unsigned cnt = 0;
+    HIPCHECK(hipMemcpy(&cnt, h->d_probe_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    const long long have = std::min<long long>(cnt, h->probe_cap);
+    std::vector<unsigned long long> v((size_t)have);
+    if (have > 0) HIPCHECK(hipMemcpy(v.data(), h->d_probe, (size_t)have * 8, hipMemcpyDeviceToHost));
+    std::sort(v.begin(), v.end());
+    const long long nw = std::min<long long>(have, cap);
+    for (long long i = 0; i < nw; i++) {
+        if (type_slot) type_slot[i] = (int32_t)(v[i] >> 56);
+        if (index) index[i] = (int64_t)(v[i] & ((1ull << 56) - 1ull));
+    }
+    return (int64_t)cnt;
+}
+
 static long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; return p; }
 
 int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_calcs,
                         double target_density) {
     if (!h) return fail(-1, "null handle");
-    if (n_calcs < 1 || n_calcs > MAXCALC) return fail(-2, "number of calculations must be in [1,32]");
+    if (n_calcs < 1 || n_calcs > MAXCALC)
+        return fail(-2, "number of calculations must be in [1,32]: the per-halo state of every calculation lives in LDS; split a "
+                        "longer list into several runs, each starting with the bound subhalo");
     if (!calcs) return fail(-3, "null calcs");
     if (calcs[0].kind != SOAP_CALC_SUBHALO)
         return fail(-4, "the first calculation must be the bound subhalo (compute_halo_properties.py:232-247)");
@@ -1281,6 +1395,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.halo.n = h->n_halo; P.halo.cofp = h->d_cofp; P.halo.search_radius = h->d_search; P.halo.read_radius = h->d_read;
     P.halo.index = h->d_index; P.halo.is_central = h->d_central; P.halo.nr_bound = h->d_nrbound;
     P.halo.status = h->d_status; P.halo.stats = h->d_stats; P.halo.todo = nullptr; P.halo.n_todo = 0;
+    P.halo.resident = h->d_resident;
+    P.probe_row = h->probe_row; P.probe_calc = h->probe_calc; P.probe_cap = h->probe_cap;
+    P.probe_out = h->d_probe; P.probe_count = h->d_probe_count;
+    if (h->probe_row >= 0) {
+        if (h->probe_calc >= n_calcs || calcs[h->probe_calc].kind == SOAP_CALC_PROJECTED)
+            return fail(-9, "member probe: calculation out of range or a projected aperture");
+        HIPCHECK(hipMemsetAsync(h->d_probe_count, 0, sizeof(unsigned), st));
+    }
     P.boxsize = h->cfg.boxsize; P.G_eff = h->cfg.G_eff; P.nu_density = h->cfg.nu_density; P.mpc20 = h->cfg.mpc20;
     P.a = h->cfg.a; P.mpc = h->cfg.mpc;
     P.G_phys = h->cfg.G_phys; P.hubble = h->cfg.hubble; P.rdot_omega = h->cfg.rdot_omega;

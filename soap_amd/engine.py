@@ -55,6 +55,10 @@ def _ptr(x, dtype, shape_tail=()):
             raise TypeError(f"expected torch dtype {tdt}, got {x.dtype}")
         if not x.is_contiguous():
             x = x.contiguous()
+        if x.is_cuda:
+            # the engine reads device inputs on its own streams, which are ordered after the legacy default stream
+            # only: whatever produced (or just widened / copied) this tensor on torch's current stream has to be done
+            torch.cuda.current_stream(x.device).synchronize()
         return C.c_void_p(x.data_ptr()), bool(x.is_cuda), x
     a = np.ascontiguousarray(x, dtype=dtype)
     return C.c_void_p(a.ctypes.data), False, a
@@ -165,7 +169,9 @@ class Engine:
         self._check(self._lib.soap_engine_stage_neutrinos(self._h, n, p_pos, p_m, p_w, int(resolution), 1 if dev else 0))
         self._staged["nu"] = (k2,) if dev else None
 
-    def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part):
+    def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part, resident_radius=None):
+        """`resident_radius` (optional, per halo, >= read_radius): how far around the centre the staged particles
+        are complete; lets the engine apply read-radius updates itself (soap_engine_set_resident_radius)."""
         n = int(np.asarray(index).shape[0])
         a = [
             np.ascontiguousarray(cofp, dtype=np.float64).reshape(n, 3),
@@ -179,9 +185,37 @@ class Engine:
             self._lib.soap_engine_stage_halos(self._h, n, *[C.c_void_p(x.ctypes.data) for x in a])
         )
         self.n_halo = n
+        if resident_radius is not None and n > 0:
+            rr = np.ascontiguousarray(np.broadcast_to(np.asarray(resident_radius, dtype=np.float64), (n,)))
+            if np.any(rr < a[2]):
+                raise ValueError("resident_radius must be >= read_radius")
+            self._check(self._lib.soap_engine_set_resident_radius(self._h, C.c_void_p(rr.ctypes.data)))
+
+    # -- verification probe ----------------------------------------------------------------
+    def set_member_probe(self, row, calc, cap=1 << 22):
+        """Record, during the next run, which staged particles calculation number `calc` of halo row `row` sums over
+        (row=None switches the probe off)."""
+        self._check(self._lib.soap_engine_set_member_probe(self._h, -1 if row is None else int(row), int(calc), int(cap)))
+
+    def fetch_members(self, cap=1 << 22):
+        """(type_slot, index in the staged arrays of that type) of the probed calculation's members, sorted."""
+        ts = np.zeros(cap, dtype=np.int32)
+        ix = np.zeros(cap, dtype=np.int64)
+        n = self._lib.soap_engine_fetch_members(self._h, C.c_void_p(ts.ctypes.data), C.c_void_p(ix.ctypes.data), cap)
+        if n < 0:
+            raise EngineError(f"fetch_members failed: {_lib.last_error()}")
+        if n > cap:
+            raise EngineError(f"member probe capacity {cap} too small for {n} members")
+        return ts[:n].copy(), ix[:n].copy()
 
     # -- run / fetch -------------------------------------------------------------------
+    MAX_CALCULATIONS = 32   # MAXCALC of the kernels: per-calculation state of a halo lives in LDS
+
     def run(self, calcs: Sequence[CalcDesc], target_density):
+        if len(calcs) > self.MAX_CALCULATIONS:
+            raise EngineError(
+                f"{len(calcs)} calculations in halo_prop_list, the engine takes at most {self.MAX_CALCULATIONS} per run: "
+                "split the list into several runs, each starting with the bound subhalo (INTEGRATION.md)")
         arr = (CalcDesc * len(calcs))(*calcs)
         td = -1.0 if target_density is None else float(target_density)
         self._check(self._lib.soap_engine_run(self._h, arr, len(calcs), td))

@@ -39,6 +39,11 @@ class ApertureProperties(HaloProperty):
         self.halo_filter = halo_filter
         self.property_filters = _property_filters(parameters, self)
         self.all_radii_kpc = list(all_radii_kpc)
+        # parameters.strict_halo_copy() (aperture_properties.py:3953, :4117-4120): a copied sphere leaves the
+        # properties with a direct dependence on the aperture size at zero.  In ApertureProperties.property_names
+        # those are the four StellarInertiaTensor* entries (:3716-3873), none of which this engine emits: the
+        # switch is read and kept, and changes no column of a spherical aperture.
+        self.strict_halo_copy = bool(parameters.strict_halo_copy()) if hasattr(parameters, "strict_halo_copy") else False
         self.aperture_physical_radius_kpc = aperture_physical_radius_kpc
         self.aperture_property = None
         self.inclusive = inclusive

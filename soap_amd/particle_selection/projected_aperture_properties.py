@@ -34,6 +34,10 @@ class ProjectedApertureProperties(HaloProperty):
         self.halo_filter = halo_filter
         self.property_filters = _property_filters(parameters, self)
         self.all_radii_kpc = list(all_radii_kpc)
+        # parameters.strict_halo_copy() (projected_aperture_properties.py:1742, :1880-1883): a copied aperture leaves
+        # the iterative 2D inertia tensors (Projected{Total,Gas,Stellar}InertiaTensor{,Reduced}: `True` in
+        # property_names, :1596-1676) at zero; the engine gets the switch as SOAP_CALC_FLAG_STRICT_COPY
+        self.strict_halo_copy = bool(parameters.strict_halo_copy()) if hasattr(parameters, "strict_halo_copy") else False
         self.aperture_physical_radius_kpc = aperture_physical_radius_kpc
         self.physical_radius_mpc = 0.001 * aperture_physical_radius_kpc
         aperture_name = _aperture_name(aperture_physical_radius_kpc)
@@ -56,6 +60,8 @@ class ProjectedApertureProperties(HaloProperty):
             if d.parent < 0:
                 raise RuntimeError(f"{prev_group} must be computed before {self.group_name}")
             d.prev_radius = self.cellgrid.kpc_to_comoving(r_prev)
+        if self.strict_halo_copy:
+            d.flags |= layout.CALC_FLAG_STRICT_COPY
         return d
 
     def unpack(self, block: np.ndarray, halo_result: Dict, do_calculation=None):

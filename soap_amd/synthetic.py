@@ -70,6 +70,7 @@ def make_chunk(
     read_radius_factor: float = 8.0,
     nmin: int = 50,
     topcells: int = 16,
+    max_halo: int | None = None,
 ):
     """
     Returns (scalars, data, halos):
@@ -97,8 +98,10 @@ def make_chunk(
         return torch.randn(*shape, generator=gen, device=dev, dtype=torch.float64)
 
     # ---- halo sizes: truncated power law, slope -1.9, then rescaled --------------
+    # largest halo of the power law: 5 % of the box, at most `max_halo` particles (default 3e5: the BASELINE
+    # configurations; bench.py --workload giant lifts it to 1e6)
     alpha = 1.9
-    nmax = max(4 * nmin, min(3.0e5, 0.05 * n_part))
+    nmax = max(4 * nmin, min(3.0e5 if max_halo is None else float(max_halo), 0.05 * n_part))
     u = rand(n_halo)
     e = 1.0 - alpha
     ntot = (nmin**e + u * (nmax**e - nmin**e)) ** (1.0 / e)
