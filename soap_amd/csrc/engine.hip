@@ -23,41 +23,7 @@
 //     projected-aperture calculation is then a prefix of it, evaluated in fused passes with
 //     lanes = calculations for everything that is per calculation;
 //   * no MFMA anywhere: the path is latency / issue bound fp64 vector work.
-#include <hip/hip_runtime.h>
-#include <chrono>
-#include <functional>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdlib.h>
-#include <math.h>
-#include <algorithm>
-#include <string>
-#include <vector>
-#include <map>
-
-#include "../../include/soap_engine.h"
-#include "device_math.h"
-#include "layout.h"
-
-#pragma clang fp contract(off)
-
-#define BLK 256
-#define NWAVE (BLK / 64)
-#define CH 4096            // LDS sort chunk (elements)
-#define PIDX_BITS 29   // packed slab index: 3 bits of type slot, 29 bits of cell-ordered position
-#define PIDX_MASK ((1u << PIDX_BITS) - 1u)
-#define MAXCALC 32
-
-// flags byte of a slab element
-#define FL_TYPE 0x7    // type slot 0..3, or NU_SLOT
-#define FL_BOUND 0x8
-#define FL_SAT 0x10
-#define FL_EXT 0x20
-// Neutrino particles (PartType6) are a fifth, internal type slot: they enter the SO mass profile with their
-// weighted mass and nothing else (SO_properties.py:380-395); no velocities, no group membership.
-#define NU_SLOT 4
-#define NT_ALL 5
+#include "engine_common.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -67,237 +33,6 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
         if (e_ != hipSuccess)                                                              \
             return fail(-100, std::string(#x) + ": " + hipGetErrorString(e_));             \
     } while (0)
-
-// ------------------------------------------------------------------------------------------
-// device-side views
-// ------------------------------------------------------------------------------------------
-struct TypeDev {
-    long long n;
-    int res;
-    int grnr64;
-    const double *x, *y, *z;      // coordinates in mesh-cell order (SoA): what the candidate stream reads
-    const double *vel, *mass;     // the caller's arrays (AoS velocities), indexed through `orig`; for NU_SLOT: vel = raw
-                                  // (unweighted) masses, mass = mass * weight
-    const int *grnr32;
-    const long long *grnr64p;
-    const long long *fof;
-    const unsigned *orig;         // original index of the particle at cell-ordered position p
-    const unsigned *cell_offset;  // res^3 + 1 entries
-    double pos_min[3], pos_max[3], cell_size[3];
-};
-
-struct SlabDev {
-    long long cap;
-    double *r, *m, *dx, *dy, *dz, *vx, *vy, *vz, *cum, *q, *dens, *pr;
-    unsigned *pidx, *pi;
-    unsigned char *flags;
-};
-
-struct HaloDev {
-    long long n;
-    const double *cofp;  // [n][3]
-    double *search_radius, *read_radius;
-    const long long *index;
-    const int *is_central;
-    const long long *nr_bound;
-    int *status;
-    long long *stats;  // [n][4]
-    const int *todo;   // optional list of rows to process (retry pass), or null
-    long long n_todo;
-    const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
-};
-
-struct RunParams {
-    TypeDev t[NT_ALL];
-    SlabDev slab;
-    HaloDev halo;
-    double boxsize, G_eff, nu_density, mpc20, target_density, a, mpc;
-    double G_phys, hubble, rdot_omega;   // pseudo-evolution term of the shell flow rates (soap_engine_config)
-    int literal;     // 1: rebuild the search sphere at every radius round (reference-literal path)
-    double first_factor;   // first sorted superset reaches first_factor * search_radius
-    int profile;           // 1: accumulate per-phase clocks (env SOAP_ENGINE_PROFILE)
-    int hydro;             // gas or star particles staged: the baryon kinematics are computed
-    int dm_only;           // only dark matter staged
-    int has_nu;            // neutrino particles staged
-    double soft[SOAP_NTYPES];
-    int ncalc;
-    long long ncols;
-    double *table;
-    unsigned *queue;
-    unsigned long long *phase;   // [32] accumulated s_memtime cycles of thread 0 per phase
-    const soap_calc_desc *calcs;  // device copy
-    const int *coloff;            // device: column offset per calc
-    // member probe (soap_engine_set_member_probe): halo row / calculation to record, packed (type slot << 56 | original index)
-    long long probe_row;
-    int probe_calc;
-    long long probe_cap;
-    unsigned long long *probe_out;
-    unsigned *probe_count;
-};
-
-// ------------------------------------------------------------------------------------------
-// wave / block primitives
-// ------------------------------------------------------------------------------------------
-// Cross-lane primitives on DPP (data-parallel primitives: VALU-rate lane moves inside rows of 16 lanes,
-// row broadcasts across rows).  HIP's __shfl_* lower to ds_bpermute, i.e. a round trip through the LDS
-// crossbar per 32-bit half and step -- rocprof showed the halo kernels latency-bound with most LDS
-// instructions being exactly those shuffles.
-template <int CTRL, int ROW_MASK = 0xf>
-SOAP_DEV double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-#define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
-#define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
-#define DPP_ROW_HALF_MIRROR 0x141
-#define DPP_ROW_MIRROR 0x140
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_ROR(n) (0x120 + (n))
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-
-SOAP_DEV double readlane_f64(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// gfx950 lane swaps across rows: v_permlane16_swap exchanges the odd 16-lane rows of one register with the
-// even rows of another, v_permlane32_swap the upper half of one with the lower half of another.  Fed the
-// same register twice they return (even-row data everywhere, odd-row data everywhere) resp. (lower-half data
-// everywhere, upper-half data everywhere): a cross-row butterfly step in two VALU instructions per dword,
-// no LDS crossbar (ds_bpermute) round trip.
-SOAP_DEV void rows16_f64(double v, double &even, double &odd) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    even = __hiloint2double(rh[0], rl[0]);
-    odd = __hiloint2double(rh[1], rl[1]);
-}
-SOAP_DEV void halves32_f64(double v, double &lower, double &upper) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    lower = __hiloint2double(rh[0], rl[0]);
-    upper = __hiloint2double(rh[1], rl[1]);
-}
-
-// Wave totals of FOUR values for the price of one: v_permlane32_swap(x, y) leaves x = {x[0:31], y[0:31]} and
-// y = {x[32:63], y[32:63]}, so x + y holds the half-sums of x in the lower and those of y in the upper 32
-// lanes; the same step on 16-lane rows packs four values, one per row, and the in-row DPP butterfly
-// finishes all four together.  Returns a register whose row r (lanes 16r..16r+15) holds the total of v_r.
-SOAP_DEV double swap32_add(double x, double y) {
-    auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
-    auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
-}
-SOAP_DEV double swap16_add(double x, double y) {
-    auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
-    auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
-}
-SOAP_DEV double wave_sum4(double v0, double v1, double v2, double v3) {
-    double a = swap32_add(v0, v2);   // lower half: v0, upper half: v2
-    double b = swap32_add(v1, v3);   // lower half: v1, upper half: v3
-    double c = swap16_add(a, b);     // rows: v0, v1, v2, v3
-    c += dpp_f64<DPP_QUAD_XOR1>(c);
-    c += dpp_f64<DPP_QUAD_XOR2>(c);
-    c += dpp_f64<DPP_ROW_HALF_MIRROR>(c);
-    c += dpp_f64<DPP_ROW_MIRROR>(c);
-    return c;
-}
-// store the four totals of wave_sum4 into dst[k0..k3] (one lane per row writes)
-SOAP_DEV void put4(double *dst, double packed, int k0, int k1, int k2, int k3) {
-    const int lane = threadIdx.x & 63, row = lane >> 4;
-    if ((lane & 15) == 0) dst[row == 0 ? k0 : (row == 1 ? k1 : (row == 2 ? k2 : k3))] = packed;
-}
-
-// sum over the 64 lanes, same value returned to every lane (fixed association:
-// ((row0 + row1) + (row2 + row3)) of the in-row butterflies)
-SOAP_DEV double wave_sum(double v) {
-    v += dpp_f64<DPP_QUAD_XOR1>(v);
-    v += dpp_f64<DPP_QUAD_XOR2>(v);
-    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
-    v += dpp_f64<DPP_ROW_MIRROR>(v);        // every lane of a 16-lane row holds the row sum
-    double a, b;
-    rows16_f64(v, a, b);
-    v = a + b;
-    halves32_f64(v, a, b);
-    return a + b;
-}
-SOAP_DEV double wave_max(double v) {
-    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
-    v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
-    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
-    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
-    double a, b;
-    rows16_f64(v, a, b);
-    v = fmax(a, b);
-    halves32_f64(v, a, b);
-    return fmax(a, b);
-}
-SOAP_DEV long long wave_min_ll(long long v) {
-    // same butterfly on the bit pattern (a double register pair is just 64 bits here)
-    auto mn = [](long long x, long long y) { return y < x ? y : x; };
-    auto asd = [](long long x) { return __longlong_as_double(x); };
-    auto asl = [](double x) { return __double_as_longlong(x); };
-    v = mn(v, asl(dpp_f64<DPP_QUAD_XOR1>(asd(v))));
-    v = mn(v, asl(dpp_f64<DPP_QUAD_XOR2>(asd(v))));
-    v = mn(v, asl(dpp_f64<DPP_ROW_HALF_MIRROR>(asd(v))));
-    v = mn(v, asl(dpp_f64<DPP_ROW_MIRROR>(asd(v))));
-    double a, b;
-    rows16_f64(asd(v), a, b);
-    v = mn(asl(a), asl(b));
-    halves32_f64(asd(v), a, b);
-    return mn(asl(a), asl(b));
-}
-// DPP move that leaves a lane's own value where the pattern has no source lane (identity for scans with an
-// operator other than +)
-template <int CTRL, int ROW_MASK = 0xf>
-SOAP_DEV double dpp_f64_keep(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-#define DPP_WAVE_SHR1 0x138     // wave_shr:1 (whole wavefront, lane 0 keeps its value)
-// inclusive prefix arg-max inside a wave: (v, s) becomes the pair with the largest v among lanes <= this one,
-// ties going to the lowest lane ("first maximum")
-SOAP_DEV void wave_scan_argmax(double &v, double &s) {
-#define ARGMAX_STEP(CTRL, MASK) { double pv = dpp_f64_keep<CTRL, MASK>(v), ps = dpp_f64_keep<CTRL, MASK>(s); if (!(v > pv)) { v = pv; s = ps; } }
-    ARGMAX_STEP(DPP_ROW_SHR(1), 0xf)
-    ARGMAX_STEP(DPP_ROW_SHR(2), 0xf)
-    ARGMAX_STEP(DPP_ROW_SHR(4), 0xf)
-    ARGMAX_STEP(DPP_ROW_SHR(8), 0xf)
-    ARGMAX_STEP(DPP_ROW_BCAST15, 0xa)
-    ARGMAX_STEP(DPP_ROW_BCAST31, 0xc)
-#undef ARGMAX_STEP
-}
-
-// inclusive scan inside a wave (row_shr with zero fill inside rows of 16, then row broadcasts)
-SOAP_DEV double wave_scan(double v, int lane) {
-    (void)lane;
-    v += dpp_f64<DPP_ROW_SHR(1)>(v);
-    v += dpp_f64<DPP_ROW_SHR(2)>(v);
-    v += dpp_f64<DPP_ROW_SHR(4)>(v);
-    v += dpp_f64<DPP_ROW_SHR(8)>(v);
-    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);   // last lane of rows 0 and 2 into rows 1 and 3
-    v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // lane 31 into rows 2 and 3
-    return v;
-}
-
-// inclusive running maximum inside a wave (values >= 0: the zero fill of row_shr is the identity)
-SOAP_DEV double wave_scan_max(double v) {
-    v = fmax(v, dpp_f64<DPP_ROW_SHR(1)>(v));
-    v = fmax(v, dpp_f64<DPP_ROW_SHR(2)>(v));
-    v = fmax(v, dpp_f64<DPP_ROW_SHR(4)>(v));
-    v = fmax(v, dpp_f64<DPP_ROW_SHR(8)>(v));
-    v = fmax(v, dpp_f64_keep<DPP_ROW_BCAST15, 0xa>(v));
-    v = fmax(v, dpp_f64_keep<DPP_ROW_BCAST31, 0xc>(v));
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------
 // mesh build kernels  (shared_mesh.py:33-114)
@@ -582,155 +317,14 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// per-halo kernel
-// ------------------------------------------------------------------------------------------
-#define NACC 76
-#define PREFB 12        // calculations whose prefix moments are finalised together
-#define NHM 5           // half-mass weight classes: all, dark matter, gas, stars, baryons
-enum {
-    A_N0 = 0, A_N1, A_N2, A_N3,        // counts per type slot
-    A_M0 = 4, A_M1, A_M2, A_M3,        // mass per type slot
-    A_MX = 8,                          // sum m*x (3), all types
-    A_MV = 11,                         // sum m*v' (3), all types
-    A_MVD = 14,                        // sum m*v' (3), dark matter
-    A_MXD = 17,                        // sum m*x (3), dark matter
-    A_LD = 20,                         // sum m * x cross v' (3), dark matter
-    A_VV = 23,                         // sum m v'_a v'_b (6), dark matter: xx yy zz xy xz yz
-    A_LA = 29,                         // sum m * x cross v' (3), all types
-    A_MR = 32,                         // sum m*r
-    A_MRS = 33,                        // sum m*max(r, softening)
-    A_MSAT = 34, A_MEXT = 35,          // mass bound to satellites / external
-    A_NFAR = 36,                       // members with r > 1e-8 (np.isclose(r, 0) false)
-    A_RMAX = 37,                       // max r  (max-reduction)
-    // gas (type slot 0) and stars (type slot 2), only accumulated when the chunk has baryons:
-    // sum m*x (3), sum m*v' (3), sum m * x cross v' (3), sum m v'_a v'_b (6)
-    A_GMX = 38, A_GMV = 41, A_GL = 44, A_GVV = 47,
-    A_SMX = 53, A_SMV = 56, A_SL = 59, A_SVV = 62,
-    // neutrino particles inside the selection: count, raw mass, weighted mass, weighted mass * radius
-    A_NUN = 68, A_NUM = 69, A_NUW = 70, A_NUR = 71,
-    A_NSUM = 72                        // accumulators in use (the last slots of NACC are scratch)
-};
-
-#define GAS __attribute__((address_space(1)))
-
-struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexed private array)
-    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    __device__ __forceinline__ void set_range(int lo, int hi) {   // bits [lo, hi]
-        for (int k = 0; k < 4; k++) {
-            int a = lo - 64 * k, b = hi - 64 * k;
-            a = a < 0 ? 0 : a;
-            b = b > 63 ? 63 : b;
-            if (a > b) continue;
-            unsigned long long m = (b - a == 63) ? ~0ull : (((1ull << (b - a + 1)) - 1ull) << a);
-            if (k == 0) w0 |= m; else if (k == 1) w1 |= m; else if (k == 2) w2 |= m; else w3 |= m;
-        }
-    }
-    __device__ __forceinline__ int count() const { return __popcll(w0) + __popcll(w1) + __popcll(w2) + __popcll(w3); }
-    // position of the n-th set bit (n < count())
-    __device__ __forceinline__ int nth(int n) const {
-        unsigned long long w = w0;
-        int base = 0, c = __popcll(w);
-        if (n >= c) { n -= c; w = w1; base = 64; c = __popcll(w);
-            if (n >= c) { n -= c; w = w2; base = 128; c = __popcll(w);
-                if (n >= c) { n -= c; w = w3; base = 192; } } }
-        for (int q = 0; q < n; q++) w &= w - 1;
-        return base + __ffsll((long long)w) - 1;
-    }
-    __device__ __forceinline__ bool get(int q) const {
-        const int k = q >> 6;
-        const unsigned long long w = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
-        return (w >> (q & 63)) & 1ull;
-    }
-};
-
-
-// ---- three instantiations of the per-halo code (halo_kernel.inc) ---------------------------------
-// a wavefront-level "barrier": LDS and global accesses of one wave are issued in order, so only the
-// compiler and outstanding memory operations have to be fenced
-#define GRP 64
-#define GNW 1
-#define GWG 64
-#define GCH 1024
-#define SORT_NBMAX 64
-#define GLB 4
-#define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
-#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-#define GINERTIA 0
-namespace g64 {
-#include "halo_kernel.inc"
+// ---- the per-halo kernels live in halo_class.hip, one translation unit per thread-group class and variant
+#define G3T 1024
+extern "C" {
+#define SOAP_DECL_LAUNCH(name) void name(int groups, hipStream_t stream, const RunParams *params, SlabDev slab, unsigned *queue, const int *todo, long long n_todo)
+SOAP_DECL_LAUNCH(soap_launch_halo_64n); SOAP_DECL_LAUNCH(soap_launch_halo_64i);
+SOAP_DECL_LAUNCH(soap_launch_halo_256n); SOAP_DECL_LAUNCH(soap_launch_halo_256i);
+SOAP_DECL_LAUNCH(soap_launch_halo_1024n); SOAP_DECL_LAUNCH(soap_launch_halo_1024i);
 }
-#undef GINERTIA
-#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
-namespace g64i {     // stay out of the variant every other run uses)
-#include "halo_kernel.inc"
-}
-#undef GINERTIA
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GATTR
-#undef GLB
-#undef GSYNC
-
-#define GRP 256
-#define GNW 4
-#define GWG 256
-#define GCH 4096
-#define SORT_NBMAX 256
-#define GLB 2
-#define GATTR __launch_bounds__(GRP, GLB)
-#define GSYNC() __syncthreads()
-#define GINERTIA 0
-namespace g256 {
-#include "halo_kernel.inc"
-}
-#undef GINERTIA
-#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
-namespace g256i {     // stay out of the variant every other run uses)
-#include "halo_kernel.inc"
-}
-#undef GINERTIA
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GATTR
-#undef GLB
-#undef GSYNC
-
-#ifndef G3T
-#define G3T 1024   // threads of the largest class (512 threads x 256 VGPRs measured slower: 35 vs 29 ms on C3)
-#endif
-#define GRP G3T
-#define GNW (G3T / 64)
-#define GWG G3T
-#define GCH 8192
-#define SORT_NBMAX 1024
-#define GLB (G3T == 1024 ? 4 : 2)
-#define GATTR __launch_bounds__(GRP, GLB)
-#define GSYNC() __syncthreads()
-#define GINERTIA 0
-namespace g1024 {
-#include "halo_kernel.inc"
-}
-#undef GINERTIA
-#define GINERTIA 1   // the same class with the inertia tensor passes compiled in (their registers and stack
-namespace g1024i {     // stay out of the variant every other run uses)
-#include "halo_kernel.inc"
-}
-#undef GINERTIA
-#undef GRP
-#undef GNW
-#undef GWG
-#undef GCH
-#undef SORT_NBMAX
-#undef GATTR
-#undef GLB
-#undef GSYNC
 
 // Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
 // (an upper bound of what the halo kernel will have to sort).  Used to pick the thread-group class of
@@ -1521,13 +1115,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(C.start, cs));
             C.nh += (long long)todo[k].size();
             if (!want_inertia) {
-                if (k == 0) hipLaunchKernelGGL(g64::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else if (k == 1) hipLaunchKernelGGL(g256::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else hipLaunchKernelGGL(g1024::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
             } else {
-                if (k == 0) hipLaunchKernelGGL(g64i::k_halo, dim3(nwg), dim3(64), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else if (k == 1) hipLaunchKernelGGL(g256i::k_halo, dim3(nwg), dim3(256), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else hipLaunchKernelGGL(g1024i::k_halo, dim3(nwg), dim3(G3T), 0, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
+                else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
             }
             HIPCHECK(hipEventRecord(C.done, cs));
             HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
