@@ -324,6 +324,24 @@ extern "C" {
 SOAP_DECL_LAUNCH(soap_launch_halo_64n); SOAP_DECL_LAUNCH(soap_launch_halo_64i);
 SOAP_DECL_LAUNCH(soap_launch_halo_256n); SOAP_DECL_LAUNCH(soap_launch_halo_256i);
 SOAP_DECL_LAUNCH(soap_launch_halo_1024n); SOAP_DECL_LAUNCH(soap_launch_halo_1024i);
+// pipeline stages (GMODE 1: build, GMODE 2: property passes) and the radius loop with lanes = halos (stage_a.hip)
+SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b); SOAP_DECL_LAUNCH(soap_launch_halo_1024b);
+SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
+void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
+}
+
+// pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
+// back one word per halo
+__global__ void k_init_hdr(HaloHdr *hdr, long long n, const long long *off, const int *cap) {
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
+        HaloHdr z;
+        memset(&z, 0, sizeof(z));
+        z.off = off[i]; z.cap = cap[i]; z.pipe_state = PIPE_PENDING;
+        hdr[i] = z;
+    }
+}
+__global__ void k_collect_state(const HaloHdr *hdr, long long n, int *state) {
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) state[i] = hdr[i].pipe_state;
 }
 
 // Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
@@ -515,6 +533,14 @@ struct soap_engine {
         long long nh = 0;
     } cls[3];
     std::vector<long long> h_nrbound;
+    // pipeline path: arena of per-halo slab slices, one record per halo
+    SlabDev arena{};
+    long long arena_cap = 0;
+    HaloHdr *d_hdr = nullptr;
+    size_t hdr_bytes = 0;
+    hipEvent_t ev_p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double ms_build = 0, ms_stage_a = 0, ms_stage_b = 0;
+    long long n_pipeline = 0, n_single = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -545,8 +571,33 @@ static int alloc_slab(soap_engine::Class &c, long long cap, int groups) {
     return 0;
 }
 
+static void free_arena(soap_engine *h) {
+    void *ptrs[] = {h->arena.r, h->arena.m, h->arena.dx, h->arena.dy, h->arena.dz, h->arena.vx, h->arena.vy, h->arena.vz,
+                    h->arena.cum, h->arena.q, h->arena.dens, h->arena.pr, h->arena.pidx, h->arena.pi, h->arena.flags};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->arena = SlabDev{};
+    h->arena_cap = 0;
+}
+
+static int alloc_arena(soap_engine *h, long long entries) {
+    if (h->arena_cap >= entries) return 0;
+    free_arena(h);
+    const size_t ne = (size_t)(entries + entries / 8);   // head room: the next chunk is rarely exactly as large
+    double **dp[] = {&h->arena.r, &h->arena.m, &h->arena.dx, &h->arena.dy, &h->arena.dz, &h->arena.vx, &h->arena.vy,
+                     &h->arena.vz, &h->arena.cum, &h->arena.q, &h->arena.dens, &h->arena.pr};
+    h->pool.purge();   // cached staging blocks make room for the arena
+    for (double **p : dp) HIPCHECK(hipMalloc((void **)p, ne * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&h->arena.pidx, ne * sizeof(unsigned)));
+    HIPCHECK(hipMalloc((void **)&h->arena.pi, ne * sizeof(unsigned)));
+    HIPCHECK(hipMalloc((void **)&h->arena.flags, ne));
+    h->arena.cap = (long long)ne;
+    h->arena_cap = (long long)ne;
+    return 0;
+}
+
 static void free_slabs(soap_engine *h) {
     for (int k = 0; k < 3; k++) free_slab(h->cls[k]);
+    free_arena(h);
 }
 
 static int32_t create_resources(soap_engine *h);
@@ -621,6 +672,7 @@ static int32_t create_resources(soap_engine *h) {
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
+    for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
     return 0;
 }
 
@@ -660,6 +712,8 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_phase) (void)hipFree(h->d_phase);
+    if (h->d_hdr) (void)hipFree(h->d_hdr);
+    for (int k = 0; k < 5; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
     if (h->d_probe) (void)hipFree(h->d_probe);
     if (h->d_probe_count) (void)hipFree(h->d_probe_count);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -924,7 +978,10 @@ static long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1
 
 int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_calcs,
                         double target_density) {
+    static const bool trace = getenv("SOAP_ENGINE_TRACE") != nullptr;
+#define TRACE(msg) do { if (trace) { fprintf(stderr, "[soap_engine] %s\n", msg); fflush(stderr); } } while (0)
     if (!h) return fail(-1, "null handle");
+    TRACE("run: begin");
     if (n_calcs < 1 || n_calcs > MAXCALC)
         return fail(-2, "number of calculations must be in [1,32]: the per-halo state of every calculation lives in LDS; split a "
                         "longer list into several runs, each starting with the bound subhalo");
@@ -1049,6 +1106,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipStreamSynchronize(st));
         h->pool.release(d_est, (size_t)h->n_halo * 8);
     }
+    TRACE("run: estimate done");
     const auto t_host1 = std::chrono::steady_clock::now();
     // heaviest first inside every class (the reference orders by bound-particle count for the same
     // reason, chunk_tasks.py:118-120); ties keep the staged order.  One sort of packed (estimate, row) keys.
@@ -1076,15 +1134,124 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
         }
     }
+    TRACE("run: classified");
     const auto t_host2 = std::chrono::steady_clock::now();
     h->ms_host_setup = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
     h->ms_host_pre = std::chrono::duration<double, std::milli>(t_host0b - t_host0).count();
     h->ms_host_classify = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
+    // ---- three-stage pipeline: build the sorted superset of every halo in its arena slice
+    // (the class kernels, stage 1), run the radius loop of ALL halos with one lane per halo (stage_a.hip, stage 2), then
+    // the property passes (the class kernels again, stage 3).  Halos the pipeline cannot finish -- radius ties, bound
+    // counts that disagree with the catalogue, a loop that runs past the first superset -- fall through to the
+    // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
+    bool pipeline = !want_inertia && !P.has_nu && !P.literal;
+    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); pipeline = pipeline && e && atoi(e) != 0; }
+    h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
+    h->n_pipeline = 0;
+    if (trace) { fprintf(stderr, "[soap_engine] ev_p0=%p pipeline=%d st=%p\n", (void *)h->ev_p[0], (int)pipeline, (void *)st); fflush(stderr); }
+    HIPCHECK(hipEventRecord(h->ev_p[0], st));
+    TRACE("run: ev recorded");
+    for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
+    if (pipeline) {
+        TRACE("pipeline: begin");
+        const size_t n = (size_t)h->n_halo;
+        // arena slices: room for every candidate of the first superset (what k_estimate counted), a power of two where
+        // the fallback sort may pad, never below 256 entries (stage B parks per-calculation values in slab columns)
+        std::vector<long long> off(n);
+        std::vector<int> capv(n);
+        long long total = 0;
+        for (size_t i = 0; i < n; i++) {
+            long long c = std::max<long long>(est[i], 256);
+            if (c > 1024) c = next_pow2(c);
+            off[i] = total; capv[i] = (int)c; total += c;
+        }
+        int rc = alloc_arena(h, total);
+        if (rc) return rc;
+        TRACE("pipeline: arena ok");
+        if (h->hdr_bytes < n * sizeof(HaloHdr)) {
+            if (h->d_hdr) (void)hipFree(h->d_hdr);
+            h->d_hdr = nullptr;
+            HIPCHECK(hipMalloc((void **)&h->d_hdr, n * sizeof(HaloHdr)));
+            h->hdr_bytes = n * sizeof(HaloHdr);
+        }
+        long long *d_off; int *d_cap, *d_state;
+        HIPCHECK(h->pool.alloc((void **)&d_off, n * 8));
+        HIPCHECK(h->pool.alloc((void **)&d_cap, n * 4));
+        HIPCHECK(h->pool.alloc((void **)&d_state, n * 4));
+        HIPCHECK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_off, d_cap);
+        P.hdr = h->d_hdr;
+        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
+        auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after) -> int32_t {
+            const int order[3] = {2, 1, 0};
+            for (int oi = 0; oi < 3; oi++) {
+                const int k = order[oi];
+                soap_engine::Class &C = h->cls[k];
+                hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
+                if (lists[k].empty()) continue;
+                const long long nt = (long long)lists[k].size();
+                if (C.todo_cap < nt) {
+                    if (C.d_todo) (void)hipFree(C.d_todo);
+                    C.todo_cap = std::max<long long>(nt, h->n_halo);
+                    HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
+                }
+                HIPCHECK(hipStreamWaitEvent(cs, after, 0));
+                HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+                HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+                const int nwg = (int)std::min<long long>(groups[k], nt);
+                const RunParams *dp = h->d_params;
+                if (mode == 1) {
+                    if (k == 0) soap_launch_halo_64b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                    else if (k == 1) soap_launch_halo_256b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                    else soap_launch_halo_1024b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                } else {
+                    if (k == 0) soap_launch_halo_64s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                    else if (k == 1) soap_launch_halo_256s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                    else soap_launch_halo_1024s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
+                }
+                HIPCHECK(hipEventRecord(C.done, cs));
+                HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+            }
+            return 0;
+        };
+        TRACE("pipeline: hdr initialised");
+        // stage 1
+        HIPCHECK(hipEventRecord(h->ev_p[1], st));
+        rc = launch_stage(1, todo, h->ev_p[1]);
+        if (rc) return rc;
+        HIPCHECK(hipEventRecord(h->ev_p[2], st));
+        TRACE("pipeline: build launched");
+        // stage 2: every halo, one lane each
+        soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
+        hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_state);
+        HIPCHECK(hipEventRecord(h->ev_p[3], st));
+        std::vector<int> state(n);
+        HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
+        TRACE("pipeline: stage a launched");
+        HIPCHECK(hipStreamSynchronize(st));
+        TRACE("pipeline: stage a done");
+        {
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(-101, std::string("pipeline: ") + hipGetErrorString(le));
+        }
+        // stage 3 for the halos whose loop finished; the rest stays on the lists of the single-kernel path
+        std::vector<int> fin[3], rest[3];
+        for (int k = 0; k < 3; k++)
+            for (int i : todo[k]) (state[i] == PIPE_DONE ? fin[k] : rest[k]).push_back(i);
+        rc = launch_stage(2, fin, h->ev_p[3]);
+        if (rc) return rc;
+        HIPCHECK(hipEventRecord(h->ev_p[4], st));
+        TRACE("pipeline: stage b launched");
+        for (int k = 0; k < 3; k++) { h->n_pipeline += (long long)fin[k].size(); h->cls[k].nh += (long long)fin[k].size(); todo[k].swap(rest[k]); }
+        h->pool.release(d_off, n * 8); h->pool.release(d_cap, n * 4); h->pool.release(d_state, n * 4);
+    }
+    TRACE("run: single-kernel part");
+    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size());
     int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
-    for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
@@ -1154,7 +1321,30 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         for (int k = 0; k < 3; k++) todo[k].swap(next[k]);
     }
-    h->ms_halo = ms_total;
+    (void)ms_total;
+    TRACE("run: passes done");
+    {
+        // the halo phase on the device timeline: from the first launch of the run to the completion of the last kernel
+        // (host gaps between the stages and passes included)
+        for (int k = 0; k < 3; k++) {
+            HIPCHECK(hipEventRecord(h->cls[k].done, h->cls[k].stream));
+            HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
+        }
+        HIPCHECK(hipEventRecord(h->ev1, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(-101, std::string("halo kernel: ") + hipGetErrorString(le));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev_p[0], h->ev1);
+        h->ms_halo = ms;
+        if (pipeline) {
+            float a = 0, b = 0, c = 0;
+            (void)hipEventElapsedTime(&a, h->ev_p[1], h->ev_p[2]);
+            (void)hipEventElapsedTime(&b, h->ev_p[2], h->ev_p[3]);
+            (void)hipEventElapsedTime(&c, h->ev_p[3], h->ev_p[4]);
+            h->ms_build = a; h->ms_stage_a = b; h->ms_stage_b = c;
+        }
+    }
     h->ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     HIPCHECK(hipMemcpy(h->phase, h->d_phase, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
@@ -1246,6 +1436,11 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_wave")) return (double)h->cls[0].nh;
     if (!strcmp(name, "n_wg256")) return (double)h->cls[1].nh;
     if (!strcmp(name, "n_wg1024")) return (double)h->cls[2].nh;
+    if (!strcmp(name, "pipe_build")) return h->ms_build;
+    if (!strcmp(name, "pipe_stage_a")) return h->ms_stage_a;
+    if (!strcmp(name, "pipe_stage_b")) return h->ms_stage_b;
+    if (!strcmp(name, "n_pipeline")) return (double)h->n_pipeline;
+    if (!strcmp(name, "n_single")) return (double)h->n_single;
     if (!strcmp(name, "mesh")) return h->ms_mesh;
     if (!strcmp(name, "reorder")) return h->ms_reorder;
     return -1.0;

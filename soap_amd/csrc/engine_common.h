@@ -77,6 +77,41 @@ struct HaloDev {
     const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
 };
 
+// Per-halo record of the three-stage pipeline (build -> radius loop -> property passes): what the stages hand to
+// each other.  The sorted slab of a halo lives in its own slice [off, off + cap) of the arena (same columns as
+// the per-group slabs of the single-kernel path).
+#define PIPE_PENDING 0
+#define PIPE_BUILT 1         // sorted superset in the arena, header filled
+#define PIPE_DONE 2          // radius loop finished: status / selections final
+#define PIPE_NEED_SUPERSET 3 // the loop ran past the superset: build again out to R_need
+#define PIPE_FALLBACK 4      // this halo goes to the single-kernel path (radius ties, inconsistent bound counts, ...)
+struct HaloHdr {
+    long long off;          // first arena entry of this halo
+    int cap;                // arena entries reserved
+    int pipe_state;
+    // ---- written by the build stage
+    int n_have;             // particles in the sorted superset (every particle with r2 <= R_have^2)
+    int q_sorted;           // minimum-image r^2 is non-decreasing in slab order
+    double R_have;
+    double R_build;         // radius to build the superset out to (0: the default first superset)
+    double shift[3];        // velocity of the innermost particle
+    long long fof0;         // its FOF id
+    int i_firstpos;         // first entry with r > 0 (n_have if none)
+    int i_lastbound;        // last entry bound to the halo (-1 if none)
+    int i_firstdm;          // first dark matter entry (n_have if none)
+    int n_restart;
+    double nb[4];           // bound particles per type slot in the superset
+    double encl;            // radius of the outermost bound particle
+    int cs_fb[MAXCALC];     // per SO density calculation (in list order of those): first entry >= 1 not above its threshold
+    // ---- written by the radius loop
+    int status;
+    int n_final;            // particles in the final search sphere
+    long long n_loop;
+    double R_final, R_search, R_read, R_need;
+    int cs_state[MAXCALC], cs_n[MAXCALC];
+    double cs_R[MAXCALC], cs_M[MAXCALC];
+};
+
 struct RunParams {
     TypeDev t[NT_ALL];
     SlabDev slab;
@@ -103,6 +138,7 @@ struct RunParams {
     long long probe_cap;
     unsigned long long *probe_out;
     unsigned *probe_count;
+    HaloHdr *hdr;                 // pipeline path: one record per staged halo (null on the single-kernel path)
 };
 
 // ------------------------------------------------------------------------------------------

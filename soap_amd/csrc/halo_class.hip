@@ -1,5 +1,5 @@
 // One thread-group class of the per-halo kernels (halo_kernel.inc), selected with -DGCLASS=64|256|1024 and
-// -DGINERTIA=0|1: compiled as separate translation units so that the classes build in parallel.  Exports a plain
+// -DGINERTIA=0|1, -DGMODE=0|1|2 (single kernel / pipeline build stage / pipeline property stage): compiled as separate translation units so that the classes build in parallel.  Exports a plain
 // launcher per variant; engine.hip owns everything on the host side.
 #include "engine_common.h"
 
@@ -39,9 +39,16 @@
 
 #define SOAP_CAT3_(a, b, c) a##b##c
 #define SOAP_CAT3(a, b, c) SOAP_CAT3_(a, b, c)
-#if GINERTIA
-#define SOAP_VARIANT i      // the same class with the inertia tensor passes compiled in (their registers and stack
-#else                       // stay out of the variant every other run uses)
+#ifndef GMODE
+#define GMODE 0
+#endif
+#if GMODE == 1
+#define SOAP_VARIANT b      // pipeline stage 1: build the sorted superset in the arena
+#elif GMODE == 2
+#define SOAP_VARIANT s      // pipeline stage 3: the property passes
+#elif GINERTIA
+#define SOAP_VARIANT i      // the single-kernel path with the inertia tensor passes compiled in (their registers and
+#else                       // stack stay out of the variant every other run uses)
 #define SOAP_VARIANT n
 #endif
 

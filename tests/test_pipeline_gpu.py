@@ -1,0 +1,93 @@
+"""
+The three-stage pipeline (build -> radius loop with one lane per halo -> property passes) against
+the single-kernel path and against the oracle.  Same sorted slabs, same property passes: the two paths must give
+the same table bit for bit, the same number of radius iterations and the same search spheres.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from soap_amd import compute_halo_properties as chp
+from soap_amd.core import halo_tasks
+from soap_amd.core.category_filter import CategoryFilter
+from soap_amd.synthetic import make_chunk, to_numpy
+from tests import helpers
+from tests.test_parity_gpu import compare_halo
+
+pytestmark = pytest.mark.gpu
+
+
+class _NoInertia:
+    """parameter-file stand-in: everything on except the inertia tensors (their iterative passes keep a run on the
+    single-kernel path)"""
+
+    def get_property_filters(self, base_halo_type, names):
+        return {n: (False if "InertiaTensor" in n else "basic") for n in names}
+
+    def strict_halo_copy(self):
+        return False
+
+
+def _run(engine, props, sc, halos_np, pipeline, resident=None):
+    os.environ["SOAP_ENGINE_PIPELINE"] = "1" if pipeline else "0"
+    try:
+        ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(len(halos_np["index"]), dtype=np.int32))
+        results = []
+        out = halo_tasks.process_halos(engine, props, sc, ha, results, resident_radius=resident)
+        table = engine.fetch(table=True)["table"]
+        return ha, results, out[4], table, (engine.kernel_ms("n_pipeline"), engine.kernel_ms("n_single"))
+    finally:
+        os.environ.pop("SOAP_ENGINE_PIPELINE", None)
+
+
+@pytest.mark.parametrize("hydro,seed,read_factor", [(False, 41, 8.0), (True, 42, 8.0), (False, 43, 1.5)])
+def test_pipeline_equals_single_kernel_path_and_oracle(built_library, hydro, seed, read_factor):
+    sc, data, halos = make_chunk(250000, 180, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=read_factor)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=not hydro)
+    ap_vars = chp.aperture_variations((30.0, 50.0, 100.0))
+    pj_vars = chp.projected_variations((30.0, 100.0)) if hydro else {}
+    props = chp.build_halo_prop_list(sc, cf, None, ap_vars, projected_vars=pj_vars, parameters=_NoInertia())
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha1, res1, raw1, t1, (np1, ns1) = _run(engine, props, sc, halos_np, pipeline=False)
+    ha2, res2, raw2, t2, (np2, ns2) = _run(engine, props, sc, halos_np, pipeline=True)
+    assert np1 == 0 and np2 > 0.8 * len(halos_np["index"]), (np1, np2, ns2)
+    assert np.array_equal(raw1["status"], raw2["status"])
+    assert np.array_equal(ha1["done"], ha2["done"])
+    assert np.array_equal(ha1["read_radius"], ha2["read_radius"])
+    assert np.array_equal(ha1["search_radius"], ha2["search_radius"])
+    assert np.array_equal(raw1["stats"][:, :3], raw2["stats"][:, :3])   # n_loop, n_sel, n_cand
+    assert np.array_equal(t1, t2)
+    if read_factor < 2.0:
+        assert np.any(raw2["status"] == 1)   # this chunk has halos that need a larger read radius
+        # with the box declared resident both paths finish them in the same call, again identically
+        ha3, _, raw3, t3, _ = _run(engine, props, sc, halos_np, pipeline=False, resident=np.inf)
+        ha4, _, raw4, t4, (np4, ns4) = _run(engine, props, sc, halos_np, pipeline=True, resident=np.inf)
+        assert np.all(ha3["done"] == 1) and np.all(ha4["done"] == 1)
+        assert np.array_equal(ha3["read_radius"], ha4["read_radius"]) and np.array_equal(ha3["search_radius"], ha4["search_radius"])
+        assert np.array_equal(raw3["stats"][:, :2], raw4["stats"][:, :2])
+        scale = np.maximum(np.abs(t3).max(axis=0, keepdims=True), 1e-300)
+        assert np.all(np.abs(t3 - t4) <= 1e-11 * np.abs(t3) + 1e-13 * scale)   # a rebuilt halo may change thread-group class
+    engine.close()
+    # and the oracle
+    from oracle import halo_oracle as ho
+
+    saved = ho.ENABLE_INERTIA
+    ho.ENABLE_INERTIA = False
+    try:
+        ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, None, ap_vars, projected_vars=pj_vars)
+    finally:
+        ho.ENABLE_INERTIA = saved
+    assert np.array_equal(ha2["done"], ha_ref["done"])
+    done_rows = np.flatnonzero(ha2["done"] == 1)
+    assert len(res2) == len(done_rows) == len(ref)
+    for j, row in enumerate(done_rows):
+        o = {k: v for k, v in ref[row].items() if "InertiaTensor" not in k}
+        hr = res2[j]
+        compare_halo(o, hr, sc) if not hydro else None
+    st = raw2["stats"][raw2["status"] == 0]
+    assert np.array_equal(st[:, 0], [s["n_loop"] for s in stats])
+    assert np.array_equal(st[:, 1], [s["n_sel"] for s in stats])
