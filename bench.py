@@ -422,7 +422,12 @@ def main():
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
                           "reorder": float(np.mean(ms_reorder)),
                           "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),
-                          "halo_wg1024": engine.kernel_ms("halo_wg1024")},
+                          "halo_wg1024": engine.kernel_ms("halo_wg1024"),
+                          "pipe_build": engine.kernel_ms("pipe_build"), "pipe_stage_a": engine.kernel_ms("pipe_stage_a"),
+                          "pipe_stage_b": engine.kernel_ms("pipe_stage_b"),
+                          "pipe_build_by_class": [engine.kernel_ms("pipe_build_" + c) for c in ("wave", "wg256", "wg1024")],
+                          "pipe_props_by_class": [engine.kernel_ms("pipe_props_" + c) for c in ("wave", "wg256", "wg1024")]},
+            "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single"))},
             "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
                                 int(engine.kernel_ms("n_wg1024"))],
             "roofline": {

@@ -328,20 +328,33 @@ SOAP_DECL_LAUNCH(soap_launch_halo_1024n); SOAP_DECL_LAUNCH(soap_launch_halo_1024
 SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b); SOAP_DECL_LAUNCH(soap_launch_halo_1024b);
 SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
+void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
+                        const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock);
 }
 
 // pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
 // back one word per halo
-__global__ void k_init_hdr(HaloHdr *hdr, long long n, const long long *off, const int *cap) {
+__global__ void k_init_hdr(HaloHdr *hdr, long long n, const long long *off, const int *cap, const double *rbuild) {
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
         HaloHdr z;
         memset(&z, 0, sizeof(z));
-        z.off = off[i]; z.cap = cap[i]; z.pipe_state = PIPE_PENDING;
+        z.off = off[i]; z.cap = cap[i]; z.pipe_state = PIPE_PENDING; z.R_build = rbuild[i];
         hdr[i] = z;
     }
 }
-__global__ void k_collect_state(const HaloHdr *hdr, long long n, int *state) {
-    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) state[i] = hdr[i].pipe_state;
+// one word per halo for the host, and for the halos whose radius loop ran past the superset the radius to build the next
+// one out to: a round and a bit (x 1.25) beyond what the loop asked for, as far as the region that is resident allows
+__global__ void k_collect_state(const RunParams *Pp, HaloHdr *hdr, long long n, int *state, double *rbuild) {
+    const RunParams &P = *Pp;
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
+        const int s = hdr[i].pipe_state;
+        state[i] = s;
+        if (s == PIPE_NEED_SUPERSET) {
+            const double limit = fmax(P.halo.read_radius[i], P.halo.resident ? P.halo.resident[i] : 0.0);
+            rbuild[i] = fmin(limit, 1.25 * hdr[i].R_need);
+        }
+        hdr[i].pipe_state = (s == PIPE_BUILT) ? PIPE_PENDING : s;   // never looked at again unless it is rebuilt
+    }
 }
 
 // Cheap work estimate per halo: particles in the mesh cells overlapped by the first sorted superset
@@ -350,12 +363,13 @@ __global__ void k_collect_state(const HaloHdr *hdr, long long n, int *state) {
 // next to a giant (their search sphere swallows the giant's cells).
 // one wavefront per halo: the lanes share the (k, j) mesh rows of the sphere's bounding cells, so the
 // dependent cell_offset lookups of one halo are in flight together
-__global__ void k_estimate(const RunParams *Pp, long long *est) {
+__global__ void k_estimate(const RunParams *Pp, long long *est, const double *rbuild) {
     const RunParams &P = *Pp;
     const int lane = threadIdx.x & 63;
     long long h = blockIdx.x * (long long)(BLK / 64) + (threadIdx.x >> 6);
     if (h >= P.halo.n) return;
     double R = fmin(P.halo.read_radius[h], P.halo.search_radius[h] * P.first_factor);
+    if (rbuild && rbuild[h] > 0.0) R = rbuild[h];   // pipeline: the halo is built again out to this radius
     long long tot = 0;
     for (int ts = 0; ts < NT_ALL; ts++) {
         const TypeDev &T = P.t[ts];
@@ -529,6 +543,8 @@ struct soap_engine {
         long long todo_cap = 0;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr, start = nullptr;
+        hipEvent_t pstart[2] = {nullptr, nullptr}, pdone[2] = {nullptr, nullptr};   // pipeline stages 1 and 3
+        double pms[2] = {0.0, 0.0};
         double ms = 0.0;
         long long nh = 0;
     } cls[3];
@@ -538,7 +554,13 @@ struct soap_engine {
     long long arena_cap = 0;
     HaloHdr *d_hdr = nullptr;
     size_t hdr_bytes = 0;
-    hipEvent_t ev_p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GBuild *d_gb = nullptr;        // scratch of the large halos' tile-parallel build
+    size_t gb_count = 0;
+    int *d_gints = nullptr;        // rows / tile tables of the large halos
+    size_t gints_count = 0;
+    double ms_gbuild = 0;
+    long long n_gbuild = 0;
+    hipEvent_t ev_p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double ms_build = 0, ms_stage_a = 0, ms_stage_b = 0;
     long long n_pipeline = 0, n_single = 0;
     // timing
@@ -668,11 +690,12 @@ static int32_t create_resources(soap_engine *h) {
         }
         HIPCHECK(hipEventCreate(&h->cls[k].done));
         HIPCHECK(hipEventCreate(&h->cls[k].start));
+        for (int q = 0; q < 2; q++) { HIPCHECK(hipEventCreate(&h->cls[k].pstart[q])); HIPCHECK(hipEventCreate(&h->cls[k].pdone[q])); }
         HIPCHECK(hipMalloc((void **)&h->cls[k].d_queue, sizeof(unsigned)));
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
-    for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
+    for (int k = 0; k < 6; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
     return 0;
 }
 
@@ -704,6 +727,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
         if (h->cls[k].d_todo) (void)hipFree(h->cls[k].d_todo);
         if (h->cls[k].done) (void)hipEventDestroy(h->cls[k].done);
         if (h->cls[k].start) (void)hipEventDestroy(h->cls[k].start);
+        for (int q = 0; q < 2; q++) { if (h->cls[k].pstart[q]) (void)hipEventDestroy(h->cls[k].pstart[q]); if (h->cls[k].pdone[q]) (void)hipEventDestroy(h->cls[k].pdone[q]); }
         if (h->cls[k].stream) (void)hipStreamDestroy(h->cls[k].stream);
     }
     if (h->d_table) (void)hipFree(h->d_table);
@@ -713,7 +737,9 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->d_hdr) (void)hipFree(h->d_hdr);
-    for (int k = 0; k < 5; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
+    if (h->d_gb) (void)hipFree(h->d_gb);
+    if (h->d_gints) (void)hipFree(h->d_gints);
+    for (int k = 0; k < 6; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
     if (h->d_probe) (void)hipFree(h->d_probe);
     if (h->d_probe_count) (void)hipFree(h->d_probe_count);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1101,7 +1127,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     {
         long long *d_est;
         HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
-        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est);
+        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
         HIPCHECK(hipMemcpyAsync(est.data(), d_est, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         h->pool.release(d_est, (size_t)h->n_halo * 8);
@@ -1148,6 +1174,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     { const char *e = getenv("SOAP_ENGINE_PIPELINE"); pipeline = pipeline && e && atoi(e) != 0; }
     h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
     h->n_pipeline = 0;
+    h->n_gbuild = 0;
     if (trace) { fprintf(stderr, "[soap_engine] ev_p0=%p pipeline=%d st=%p\n", (void *)h->ev_p[0], (int)pipeline, (void *)st); fflush(stderr); }
     HIPCHECK(hipEventRecord(h->ev_p[0], st));
     TRACE("run: ev recorded");
@@ -1155,32 +1182,18 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (pipeline) {
         TRACE("pipeline: begin");
         const size_t n = (size_t)h->n_halo;
-        // arena slices: room for every candidate of the first superset (what k_estimate counted), a power of two where
-        // the fallback sort may pad, never below 256 entries (stage B parks per-calculation values in slab columns)
-        std::vector<long long> off(n);
-        std::vector<int> capv(n);
-        long long total = 0;
-        for (size_t i = 0; i < n; i++) {
-            long long c = std::max<long long>(est[i], 256);
-            if (c > 1024) c = next_pow2(c);
-            off[i] = total; capv[i] = (int)c; total += c;
-        }
-        int rc = alloc_arena(h, total);
-        if (rc) return rc;
-        TRACE("pipeline: arena ok");
         if (h->hdr_bytes < n * sizeof(HaloHdr)) {
             if (h->d_hdr) (void)hipFree(h->d_hdr);
             h->d_hdr = nullptr;
             HIPCHECK(hipMalloc((void **)&h->d_hdr, n * sizeof(HaloHdr)));
             h->hdr_bytes = n * sizeof(HaloHdr);
         }
-        long long *d_off; int *d_cap, *d_state;
+        long long *d_off, *d_est2; int *d_cap, *d_state; double *d_rbuild;
         HIPCHECK(h->pool.alloc((void **)&d_off, n * 8));
+        HIPCHECK(h->pool.alloc((void **)&d_est2, n * 8));
         HIPCHECK(h->pool.alloc((void **)&d_cap, n * 4));
         HIPCHECK(h->pool.alloc((void **)&d_state, n * 4));
-        HIPCHECK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_off, d_cap);
+        HIPCHECK(h->pool.alloc((void **)&d_rbuild, n * 8));
         P.hdr = h->d_hdr;
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
         auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after) -> int32_t {
@@ -1201,6 +1214,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
                 const int nwg = (int)std::min<long long>(groups[k], nt);
                 const RunParams *dp = h->d_params;
+                HIPCHECK(hipEventRecord(C.pstart[mode == 1 ? 0 : 1], cs));
                 if (mode == 1) {
                     if (k == 0) soap_launch_halo_64b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                     else if (k == 1) soap_launch_halo_256b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
@@ -1210,41 +1224,167 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     else if (k == 1) soap_launch_halo_256s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                     else soap_launch_halo_1024s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                 }
+                HIPCHECK(hipEventRecord(C.pdone[mode == 1 ? 0 : 1], cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
                 HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+                if (C.pms[mode == 1 ? 0 : 1] == 0.0) C.pms[mode == 1 ? 0 : 1] = -1.0;   // first iteration: measured after the run
             }
             return 0;
         };
-        TRACE("pipeline: hdr initialised");
-        // stage 1
-        HIPCHECK(hipEventRecord(h->ev_p[1], st));
-        rc = launch_stage(1, todo, h->ev_p[1]);
-        if (rc) return rc;
-        HIPCHECK(hipEventRecord(h->ev_p[2], st));
-        TRACE("pipeline: build launched");
-        // stage 2: every halo, one lane each
-        soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
-        hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_state);
-        HIPCHECK(hipEventRecord(h->ev_p[3], st));
-        std::vector<int> state(n);
-        HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
-        TRACE("pipeline: stage a launched");
-        HIPCHECK(hipStreamSynchronize(st));
-        TRACE("pipeline: stage a done");
-        {
-            hipError_t le = hipGetLastError();
-            if (le != hipSuccess) return fail(-101, std::string("pipeline: ") + hipGetErrorString(le));
+        for (int k = 0; k < 3; k++) h->cls[k].pms[0] = h->cls[k].pms[1] = 0.0;
+        // stage times: summed over the iterations (read once the iteration's last kernel is through); per class: first iteration
+        auto collect_times = [&]() {
+            float a = 0, b = 0, c = 0;
+            (void)hipEventElapsedTime(&a, h->ev_p[1], h->ev_p[2]);
+            (void)hipEventElapsedTime(&b, h->ev_p[2], h->ev_p[3]);
+            (void)hipEventElapsedTime(&c, h->ev_p[3], h->ev_p[4]);
+            h->ms_build += a; h->ms_stage_a += b; h->ms_stage_b += c;
+            for (int k = 0; k < 3; k++)
+                for (int q = 0; q < 2; q++)
+                    if (h->cls[k].pms[q] < 0.0) { float m = 0; (void)hipEventElapsedTime(&m, h->cls[k].pstart[q], h->cls[k].pdone[q]); h->cls[k].pms[q] = m > 0 ? m : 1e-6; }
+        };
+        std::vector<double> rbuild(n, 0.0);         // 0: the default first superset
+        std::vector<int> state(n), single[3];       // rows that end up on the single-kernel path
+        std::vector<long long> off(n);
+        std::vector<int> capv(n);
+        // Iterations: every halo goes through build -> radius loop -> property passes; a halo whose loop ran past its
+        // superset is built again, further out (twice the radius the loop had reached, the region that is resident
+        // permitting), in the next iteration -- the arena is laid out afresh for the halos of each iteration.
+        { const char *e = getenv("SOAP_ENGINE_PIPE_ONLY_CLASS"); if (e) for (int k = 0; k < 3; k++) if (k != atoi(e)) todo[k].clear(); }   // diagnostics
+        for (int iter = 0; iter < 8; iter++) {
+            if (iter > 0 && getenv("SOAP_ENGINE_PIPE_ONE_ITER")) { for (int k = 0; k < 3; k++) todo[k].clear(); break; }   // diagnostics
+            long long nrows = 0;
+            for (int k = 0; k < 3; k++) nrows += (long long)todo[k].size();
+            if (nrows == 0) break;
+            if (iter > 0) {
+                // new work estimates for the enlarged spheres; the classes follow them
+                HIPCHECK(hipMemcpyAsync(d_rbuild, rbuild.data(), n * 8, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est2, (const double *)d_rbuild);
+                HIPCHECK(hipMemcpyAsync(est.data(), d_est2, n * 8, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                std::vector<int> again[3];
+                for (int k = 0; k < 3; k++)
+                    for (int i : todo[k]) {
+                        const long long nb = std::min<long long>(std::max<long long>(est[i], 0), 0xffffffffLL);
+                        again[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back(i);
+                    }
+                for (int k = 0; k < 3; k++) {
+                    std::sort(again[k].begin(), again[k].end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
+                    todo[k].swap(again[k]);
+                }
+            }
+            // arena slices: room for every candidate of the superset (what k_estimate counted), a power of two where
+            // the fallback sort may pad, never below 256 entries (stage B parks per-calculation values in slab columns)
+            long long total = 0;
+            for (int k = 0; k < 3; k++)
+                for (int i : todo[k]) {
+                    long long c = std::max<long long>(est[i], 256);
+                    if (c > 1024) c = next_pow2(c);
+                    off[i] = total; capv[i] = (int)c; total += c;
+                }
+            int rc = alloc_arena(h, total);
+            if (rc) return rc;
+            HIPCHECK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
+            if (iter == 0) HIPCHECK(hipMemsetAsync(d_rbuild, 0, n * 8, st));
+            hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_off, d_cap, (const double *)d_rbuild);
+            // stage 1: small halos one thread group each; large halos (everything beyond the wavefront class) with
+            // several workgroups per halo (k_g* kernels), on the stream of the 1024-thread class
+            HIPCHECK(hipEventRecord(h->ev_p[1], st));
+            std::vector<int> small_lists[3], none;
+            bool gbuild = getenv("SOAP_ENGINE_GBUILD") == nullptr || atoi(getenv("SOAP_ENGINE_GBUILD")) != 0;
+            if (gbuild) small_lists[0] = todo[0];
+            else for (int k = 0; k < 3; k++) small_lists[k] = todo[k];
+            rc = launch_stage(1, small_lists, h->ev_p[1]);
+            if (rc) return rc;
+            if (gbuild && (!todo[1].empty() || !todo[2].empty())) {
+                std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, tile_li, gblock_li;
+                for (int k = 1; k < 3; k++) rows.insert(rows.end(), todo[k].begin(), todo[k].end());
+                const size_t L = rows.size();
+                for (size_t li = 0; li < L; li++) {
+                    const long long cap = capv[rows[li]];
+                    const int nt = (int)((cap + GTILE - 1) / GTILE);
+                    const int ng = (int)std::min<long long>(GNBMAX, std::max<long long>(2, next_pow2((cap + 1023) / 1024)));
+                    first_tile.push_back((int)tile_li.size()); ntile.push_back(nt);
+                    first_gblock.push_back((int)gblock_li.size()); ngblock.push_back(ng);
+                    tile_li.insert(tile_li.end(), (size_t)nt, (int)li);
+                    gblock_li.insert(gblock_li.end(), (size_t)ng, (int)li);
+                }
+                if (h->gb_count < L) {
+                    if (h->d_gb) (void)hipFree(h->d_gb);
+                    h->d_gb = nullptr;
+                    h->gb_count = L + L / 4 + 16;
+                    HIPCHECK(hipMalloc((void **)&h->d_gb, h->gb_count * sizeof(GBuild)));
+                }
+                const size_t nints = 5 * L + tile_li.size() + gblock_li.size();
+                if (h->gints_count < nints) {
+                    if (h->d_gints) (void)hipFree(h->d_gints);
+                    h->d_gints = nullptr;
+                    h->gints_count = nints + nints / 4 + 64;
+                    HIPCHECK(hipMalloc((void **)&h->d_gints, h->gints_count * sizeof(int)));
+                }
+                soap_engine::Class &C = h->cls[2];
+                hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
+                HIPCHECK(hipStreamWaitEvent(cs, h->ev_p[1], 0));
+                int *d = h->d_gints;
+                const std::vector<int> *parts[7] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li};
+                int *dptr[7];
+                for (int q = 0; q < 7; q++) {
+                    dptr[q] = d;
+                    HIPCHECK(hipMemcpyAsync(d, parts[q]->data(), parts[q]->size() * sizeof(int), hipMemcpyHostToDevice, cs));
+                    d += parts[q]->size();
+                }
+                P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6];
+                HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
+                HIPCHECK(hipStreamWaitEvent(h->cls[0].stream, h->ev_p[1], 0));   // (class 0 reads the same parameter block: upload first)
+                HIPCHECK(hipEventRecord(C.pstart[0], cs));
+                soap_launch_gbuild(cs, h->d_params, h->arena, (long long)L, (long long)tile_li.size(), (long long)gblock_li.size(),
+                                   dptr[0], dptr[1], dptr[2], dptr[3], dptr[4]);
+                HIPCHECK(hipEventRecord(C.pdone[0], cs));
+                HIPCHECK(hipEventRecord(C.done, cs));
+                HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+                if (C.pms[0] == 0.0) C.pms[0] = -1.0;
+                h->n_gbuild += (long long)L;
+            }
+            HIPCHECK(hipEventRecord(h->ev_p[2], st));
+            // stage 2: one lane per halo (records that are not freshly built are skipped)
+            soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
+            hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_hdr, (long long)n, d_state, d_rbuild);
+            HIPCHECK(hipEventRecord(h->ev_p[3], st));
+            HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(rbuild.data(), d_rbuild, n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            {
+                hipError_t le = hipGetLastError();
+                if (le != hipSuccess) return fail(-101, std::string("pipeline: ") + hipGetErrorString(le));
+            }
+            // stage 3 for the halos whose loop finished
+            std::vector<int> fin[3], rest[3];
+            for (int k = 0; k < 3; k++)
+                for (int i : todo[k]) {
+                    if (state[i] == PIPE_DONE) fin[k].push_back(i);
+                    else if (state[i] == PIPE_NEED_SUPERSET && iter < 7) rest[k].push_back(i);
+                    else single[k].push_back(i);
+                }
+            rc = launch_stage(2, fin, h->ev_p[3]);
+            if (rc) return rc;
+            HIPCHECK(hipEventRecord(h->ev_p[4], st));
+            for (int k = 0; k < 3; k++) { h->n_pipeline += (long long)fin[k].size(); h->cls[k].nh += (long long)fin[k].size(); todo[k].swap(rest[k]); }
+            // the arena is laid out again for the next iteration: its property passes have to be through
+            bool more = false;
+            for (int k = 0; k < 3; k++) more = more || !todo[k].empty();
+            HIPCHECK(hipStreamSynchronize(st));
+            collect_times();
+            (void)more;
+            if (trace) {
+                fprintf(stderr, "[soap_engine] pipeline iteration %d: %lld rows, finished %zu, again %zu, build %.2f ms a %.2f ms props %.2f ms (cumulative)\n", iter, nrows,
+                        fin[0].size() + fin[1].size() + fin[2].size(), todo[0].size() + todo[1].size() + todo[2].size(), h->ms_build, h->ms_stage_a, h->ms_stage_b);
+                fflush(stderr);
+            }
         }
-        // stage 3 for the halos whose loop finished; the rest stays on the lists of the single-kernel path
-        std::vector<int> fin[3], rest[3];
-        for (int k = 0; k < 3; k++)
-            for (int i : todo[k]) (state[i] == PIPE_DONE ? fin[k] : rest[k]).push_back(i);
-        rc = launch_stage(2, fin, h->ev_p[3]);
-        if (rc) return rc;
-        HIPCHECK(hipEventRecord(h->ev_p[4], st));
-        TRACE("pipeline: stage b launched");
-        for (int k = 0; k < 3; k++) { h->n_pipeline += (long long)fin[k].size(); h->cls[k].nh += (long long)fin[k].size(); todo[k].swap(rest[k]); }
-        h->pool.release(d_off, n * 8); h->pool.release(d_cap, n * 4); h->pool.release(d_state, n * 4);
+        for (int k = 0; k < 3; k++) { single[k].insert(single[k].end(), todo[k].begin(), todo[k].end()); todo[k].swap(single[k]); }
+        h->pool.release(d_off, n * 8); h->pool.release(d_est2, n * 8); h->pool.release(d_cap, n * 4);
+        h->pool.release(d_state, n * 4); h->pool.release(d_rbuild, n * 8);
     }
     TRACE("run: single-kernel part");
     h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size());
@@ -1337,13 +1477,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->ev_p[0], h->ev1);
         h->ms_halo = ms;
-        if (pipeline) {
-            float a = 0, b = 0, c = 0;
-            (void)hipEventElapsedTime(&a, h->ev_p[1], h->ev_p[2]);
-            (void)hipEventElapsedTime(&b, h->ev_p[2], h->ev_p[3]);
-            (void)hipEventElapsedTime(&c, h->ev_p[3], h->ev_p[4]);
-            h->ms_build = a; h->ms_stage_a = b; h->ms_stage_b = c;
-        }
+
     }
     h->ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     HIPCHECK(hipMemcpy(h->phase, h->d_phase, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1436,10 +1570,16 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_wave")) return (double)h->cls[0].nh;
     if (!strcmp(name, "n_wg256")) return (double)h->cls[1].nh;
     if (!strcmp(name, "n_wg1024")) return (double)h->cls[2].nh;
+    if (!strncmp(name, "pipe_build_", 11) || !strncmp(name, "pipe_props_", 11)) {
+        const int q = name[5] == 'b' ? 0 : 1;
+        const int k = !strcmp(name + 11, "wave") ? 0 : (!strcmp(name + 11, "wg256") ? 1 : (!strcmp(name + 11, "wg1024") ? 2 : -1));
+        return k < 0 ? -1.0 : h->cls[k].pms[q];
+    }
     if (!strcmp(name, "pipe_build")) return h->ms_build;
     if (!strcmp(name, "pipe_stage_a")) return h->ms_stage_a;
     if (!strcmp(name, "pipe_stage_b")) return h->ms_stage_b;
     if (!strcmp(name, "n_pipeline")) return (double)h->n_pipeline;
+    if (!strcmp(name, "n_gbuild")) return (double)h->n_gbuild;
     if (!strcmp(name, "n_single")) return (double)h->n_single;
     if (!strcmp(name, "mesh")) return h->ms_mesh;
     if (!strcmp(name, "reorder")) return h->ms_reorder;

@@ -112,6 +112,26 @@ struct HaloHdr {
     double cs_R[MAXCALC], cs_M[MAXCALC];
 };
 
+// Scratch of the tile-parallel build of one LARGE halo (several workgroups per halo, kernels k_g* of
+// halo_kernel.inc): append cursor of the selection, the sample sort's splitters / bucket fills / bucket groups, and
+// the slab facts that are reduced with atomics.
+#define GTILE 4096       // slab entries per tile (one 256-thread workgroup each)
+#define GNBMAX 1024      // most buckets of the distributed sample sort
+struct GBuild {
+    int row;             // halo row
+    int first_tile, ntile;     // tiles covering the halo's arena slice
+    int first_gblock, ngblock; // blocks of the bucket-group sort reserved for it
+    unsigned n;          // particles selected (append cursor)
+    int nb, ngroup, overflow;
+    int q_unsorted, i_firstpos, i_lastbound, i_firstdm;
+    int nbi[4];
+    int pad_;
+    double splitter[GNBMAX];
+    unsigned bcount[GNBMAX];
+    int bstart[GNBMAX + 1];
+    int gstart[GNBMAX + 1];
+};
+
 struct RunParams {
     TypeDev t[NT_ALL];
     SlabDev slab;
@@ -139,6 +159,8 @@ struct RunParams {
     unsigned long long *probe_out;
     unsigned *probe_count;
     HaloHdr *hdr;                 // pipeline path: one record per staged halo (null on the single-kernel path)
+    GBuild *gb;                   // pipeline path: scratch of the large halos' tile-parallel build
+    const int *tile_li, *gblock_li;   // tile / sort block -> entry of gb
 };
 
 // ------------------------------------------------------------------------------------------

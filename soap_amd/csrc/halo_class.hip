@@ -42,7 +42,9 @@
 #ifndef GMODE
 #define GMODE 0
 #endif
-#if GMODE == 1
+#if GMODE == 3
+#define SOAP_VARIANT g      // pipeline stage 1 for large halos: several workgroups per halo
+#elif GMODE == 1
 #define SOAP_VARIANT b      // pipeline stage 1: build the sorted superset in the arena
 #elif GMODE == 2
 #define SOAP_VARIANT s      // pipeline stage 3: the property passes
@@ -56,7 +58,29 @@ namespace {
 #include "halo_kernel.inc"
 }
 
+#if GMODE == 3
+// the whole tile-parallel build of `nlarge` large halos: ten launches on one stream, kernel boundaries are the
+// only synchronisation between the phases
+extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles,
+                                   long long ngblocks, const int *rows, const int *first_tile, const int *ntile,
+                                   const int *first_gblock, const int *ngblock) {
+    if (nlarge <= 0) return;
+    const unsigned g64 = (unsigned)((nlarge + 63) / 64);
+    hipLaunchKernelGGL(k_ginit, dim3(g64), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock);
+    hipLaunchKernelGGL(k_gselect, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gsplit, dim3((unsigned)nlarge), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_ghist, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gscan, dim3((unsigned)nlarge), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gscatter, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gsortgroups, dim3((unsigned)ngblocks), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_ggather, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gcumsum, dim3((unsigned)nlarge), dim3(64), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gpost, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
+}
+#else
 extern "C" void SOAP_CAT3(soap_launch_halo_, GCLASS, SOAP_VARIANT)(int groups, hipStream_t stream, const RunParams *params, SlabDev slab,
                                                                  unsigned *queue, const int *todo, long long n_todo) {
     hipLaunchKernelGGL(k_halo, dim3(groups), dim3(GRP), 0, stream, params, slab, queue, todo, n_todo);
 }
+#endif

@@ -42,8 +42,13 @@ def _run(engine, props, sc, halos_np, pipeline, resident=None):
         os.environ.pop("SOAP_ENGINE_PIPELINE", None)
 
 
-@pytest.mark.parametrize("hydro,seed,read_factor", [(False, 41, 8.0), (True, 42, 8.0), (False, 43, 1.5)])
-def test_pipeline_equals_single_kernel_path_and_oracle(built_library, hydro, seed, read_factor):
+@pytest.mark.parametrize("hydro,seed,read_factor,nb_small", [(False, 41, 8.0, None), (True, 42, 8.0, None), (False, 43, 1.5, None),
+                                                             (False, 44, 8.0, 600), (True, 45, 1.5, 2000)])
+def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatch, hydro, seed, read_factor, nb_small):
+    if nb_small is not None:
+        # most halos count as LARGE: their slabs are built by several workgroups each (k_g* kernels) in the pipeline,
+        # by one 256-thread group on the single-kernel path
+        monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", str(nb_small))
     sc, data, halos = make_chunk(250000, 180, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=read_factor)
     data_np, halos_np = to_numpy(data, halos)
     cf = CategoryFilter(dmo=not hydro)
@@ -55,6 +60,8 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, hydro, see
     ha1, res1, raw1, t1, (np1, ns1) = _run(engine, props, sc, halos_np, pipeline=False)
     ha2, res2, raw2, t2, (np2, ns2) = _run(engine, props, sc, halos_np, pipeline=True)
     assert np1 == 0 and np2 > 0.8 * len(halos_np["index"]), (np1, np2, ns2)
+    if nb_small is not None:
+        assert engine.kernel_ms("n_gbuild") > 0.3 * len(halos_np["index"])
     assert np.array_equal(raw1["status"], raw2["status"])
     assert np.array_equal(ha1["done"], ha2["done"])
     assert np.array_equal(ha1["read_radius"], ha2["read_radius"])
