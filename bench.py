@@ -396,7 +396,9 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 continue
-        b_reorder = wl["n_part"] * 60 if world == 1 else n_region * 60   # 24 B read + (24 + 4) B written + cell/rank traffic 8 B
+        # the placement pass: coordinates read (24 B), cell id + rank read back (8 B), coordinates written in cell order (24 B),
+        # permutation (4 B); velocities / masses / ids read (44 B) and the 80-byte payload record written
+        b_reorder = (wl["n_part"] if world == 1 else n_region) * (24 + 8 + 24 + 4 + 44 + 80)
         line = {
             "metric": "particle_aperture_evals_per_s",
             "value": evals_all * npasses / dt,
@@ -440,8 +442,9 @@ def main():
             "reorder_roofline": {
                 "achieved": b_reorder / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,
                 "unit": "GB/s", "algorithmic_bytes": b_reorder,
-                "note": "bytes the placement pass moves: coordinates read (24 B) and written in cell order (24 B), "
-                        "permutation (4 B), cell id + rank read back (8 B); velocities / masses / ids are not moved",
+                "note": "bytes the placement pass moves per particle: coordinates read (24 B) and written in cell order (24 B), "
+                        "permutation (4 B), cell id + rank read back (8 B), velocities / masses / ids read (44 B) and the "
+                        "80-byte payload record written",
             },
             "generation_s": t_gen,
             "n_loop_mean": float(stats[ok, 0].mean()), "n_sel_max": int(stats[ok, 1].max()),

@@ -256,7 +256,9 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
 // threads store to consecutive addresses -- four coalesced streams instead of four scattered 8-byte stores
 // per particle.  Launched with the grid of k_cellid (same particles per block iteration).
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
-                              unsigned *sort_idx, const double *pos, double *x, double *y, double *z) {
+                              unsigned *sort_idx, const double *pos, double *x, double *y, double *z,
+                              Pay *pay, const double *vel, const double *mass, const int *g32, const long long *g64,
+                              const long long *fof, int nu) {
     __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
@@ -308,8 +310,21 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
         __syncthreads();
         if (threadIdx.x < s_total) {
             const unsigned q = s_p[threadIdx.x];
-            sort_idx[q] = s_i[threadIdx.x];
+            const unsigned io = s_i[threadIdx.x];
+            sort_idx[q] = io;
             x[q] = s_x[threadIdx.x]; y[q] = s_y[threadIdx.x]; z[q] = s_z[threadIdx.x];
+            // the payload record of the particle (read from the block's own window of the caller's arrays)
+            Pay r;
+            r.x = s_x[threadIdx.x]; r.y = s_y[threadIdx.x]; r.z = s_z[threadIdx.x];
+            r.m = mass[io];
+            if (nu) { r.vx = vel[io]; r.vy = 0.0; r.vz = 0.0; r.grnr = -1; r.fof = -1; }
+            else {
+                r.vx = vel[3 * (long long)io]; r.vy = vel[3 * (long long)io + 1]; r.vz = vel[3 * (long long)io + 2];
+                r.grnr = g64 ? g64[io] : (long long)g32[io];
+                r.fof = fof[io];
+            }
+            r.pad_ = 0.0;
+            pay[q] = r;
         }
         __syncthreads();
         for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
@@ -329,7 +344,8 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b);
 SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
-                        const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock);
+                        long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
+                        const int *ngblock, const int *first_sel, const int *nsel);
 }
 
 // pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
@@ -343,7 +359,8 @@ __global__ void k_init_hdr(HaloHdr *hdr, long long n, const long long *off, cons
     }
 }
 // one word per halo for the host, and for the halos whose radius loop ran past the superset the radius to build the next
-// one out to: a round and a bit (x 1.25) beyond what the loop asked for, as far as the region that is resident allows
+// one out to: a round and a bit (x 1.25) beyond what the loop asked for -- three times as far once that was not enough --
+// as far as the region that is resident allows
 __global__ void k_collect_state(const RunParams *Pp, HaloHdr *hdr, long long n, int *state, double *rbuild) {
     const RunParams &P = *Pp;
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
@@ -351,7 +368,7 @@ __global__ void k_collect_state(const RunParams *Pp, HaloHdr *hdr, long long n, 
         state[i] = s;
         if (s == PIPE_NEED_SUPERSET) {
             const double limit = fmax(P.halo.read_radius[i], P.halo.resident ? P.halo.resident[i] : 0.0);
-            rbuild[i] = fmin(limit, 1.25 * hdr[i].R_need);
+            rbuild[i] = fmin(limit, (hdr[i].R_build > 0.0 ? 3.0 : 1.25) * hdr[i].R_need);   // a second miss: a halo inside a larger one's envelope, reach far
         }
         hdr[i].pipe_state = (s == PIPE_BUILT) ? PIPE_PENDING : s;   // never looked at again unless it is rebuilt
     }
@@ -449,7 +466,7 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
 struct DevPool {
     std::multimap<size_t, void *> free_blocks;   // capacity -> block
     std::map<void *, size_t> capacity;           // blocks handed out: their real size
-    size_t cached = 0, max_cached = (size_t)8 << 30;
+    size_t cached = 0, max_cached = (size_t)48 << 30;   // one generation of a 1e8-particle chunk is ~15 GB
     hipError_t alloc(void **p, size_t bytes) {
         if (bytes == 0) bytes = 8;
         auto it = free_blocks.lower_bound(bytes);
@@ -494,8 +511,10 @@ struct TypeHost {
     const long long *g64 = nullptr, *fof = nullptr;
     std::vector<std::pair<void *, size_t>> owned;   // device copies the engine made (host inputs)
     unsigned *orig = nullptr, *cell_offset = nullptr;
+    Pay *pay = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
     void release(DevPool &pool) {
+        pool.release(pay, (size_t)n * sizeof(Pay));
         void *d8[] = {x, y, z};
         for (void *p : d8) pool.release(p, (size_t)n * 8);
         for (auto &o : owned) pool.release(o.first, o.second);
@@ -884,8 +903,9 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
             T.g32 = nullptr; T.g64 = nullptr; T.fof = nullptr;
         }
         HIPCHECK(hipEventCreate(&ev2));
+        HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
         hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset, T.orig,
-                           dpos, T.x, T.y, T.z);
+                           dpos, T.x, T.y, T.z, T.pay, T.vel, T.mass, T.g32, T.g64, T.fof, nu ? 1 : 0);
         HIPCHECK(hipEventRecord(ev2, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -1065,7 +1085,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         TypeDev &D = P.t[t];
         D.n = T.n; D.res = T.res; D.grnr64 = T.grnr64;
         D.x = T.x; D.y = T.y; D.z = T.z; D.vel = T.vel; D.mass = T.mass;
-        D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset;
+        D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset; D.pay = T.pay;
         for (int d = 0; d < 3; d++) { D.pos_min[d] = T.pos_min[d]; D.pos_max[d] = T.pos_max[d]; D.cell_size[d] = T.cell_size[d]; }
         if (t < SOAP_NTYPES) P.soft[t] = h->cfg.softening[t];
     }
@@ -1119,6 +1139,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         caps[0] = c0; caps[1] = c0 * 8; caps[2] = c0 * 64;
         nb_small = c0 / 4; nb_medium = c0 * 2;
     }
+    { const char *e = getenv("SOAP_ENGINE_G0"); if (e) groups[0] = atoi(e); }
     if (h->cfg.n_workgroups > 0) { groups[0] = h->cfg.n_workgroups * 4; groups[1] = h->cfg.n_workgroups; groups[2] = std::max(1, h->cfg.n_workgroups / 4); }
     // never below 256 entries: stage B parks 3 values per calculation in two slab columns (finalize_moments)
     for (int k = 0; k < 3; k++) caps[k] = std::max(std::min(caps[k], cap_max), 256ll);
@@ -1170,7 +1191,49 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // the property passes (the class kernels again, stage 3).  Halos the pipeline cannot finish -- radius ties, bound
     // counts that disagree with the catalogue, a loop that runs past the first superset -- fall through to the
     // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
+    // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
+    auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
+        // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
+        // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
+        // (two equal-priority user streams get distinct hardware queues, three do not).
+        const int order[3] = {2, 1, 0};
+        for (int oi = 0; oi < 3; oi++) {
+            const int k = order[oi];
+            soap_engine::Class &C = h->cls[k];
+            hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
+            if (lists[k].empty()) continue;
+            const long long nt = (long long)lists[k].size();
+            const int nwg = (int)std::min<long long>(groups[k], nt);
+            int rc = alloc_slab(C, caps[k], groups[k]);
+            if (rc) return rc;
+            if (C.todo_cap < nt) {
+                if (C.d_todo) (void)hipFree(C.d_todo);
+                C.todo_cap = std::max<long long>(nt, 2 * h->n_halo);
+                HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
+            }
+            HIPCHECK(hipStreamWaitEvent(cs, after, 0));
+            HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+            const RunParams *dp = h->d_params;
+            HIPCHECK(hipEventRecord(C.start, cs));
+            C.nh += nt;
+            if (!want_inertia) {
+                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+            } else {
+                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+            }
+            HIPCHECK(hipEventRecord(C.done, cs));
+            if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+        }
+        return 0;
+    };
     bool pipeline = !want_inertia && !P.has_nu && !P.literal;
+    // SOAP_ENGINE_PIPELINE: unset / 0 the single-kernel path (the fastest on the reference configurations so far, DESIGN.md
+    // section 5.3); 1 the mix described below; 2 every halo through the pipeline
     { const char *e = getenv("SOAP_ENGINE_PIPELINE"); pipeline = pipeline && e && atoi(e) != 0; }
     h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
     h->n_pipeline = 0;
@@ -1179,6 +1242,17 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipEventRecord(h->ev_p[0], st));
     TRACE("run: ev recorded");
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
+    // Hybrid (SOAP_ENGINE_PIPELINE=1): the pipeline takes the halos of the wavefront class -- nine in ten, and what saturates the GPU on
+    // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
+    // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
+    std::vector<int> early[3];
+    bool hybrid = false;
+    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); hybrid = pipeline && !(e && atoi(e) == 2); }
+    if (hybrid) {
+        for (int k = 1; k < 3; k++) early[k].swap(todo[k]);
+        int rc = launch_single(early, h->ev_p[0], false);
+        if (rc) return rc;
+    }
     if (pipeline) {
         TRACE("pipeline: begin");
         const size_t n = (size_t)h->n_halo;
@@ -1206,7 +1280,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 const long long nt = (long long)lists[k].size();
                 if (C.todo_cap < nt) {
                     if (C.d_todo) (void)hipFree(C.d_todo);
-                    C.todo_cap = std::max<long long>(nt, h->n_halo);
+                    C.todo_cap = std::max<long long>(nt, 2 * h->n_halo);
                     HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
                 }
                 HIPCHECK(hipStreamWaitEvent(cs, after, 0));
@@ -1266,7 +1340,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 for (int k = 0; k < 3; k++)
                     for (int i : todo[k]) {
                         const long long nb = std::min<long long>(std::max<long long>(est[i], 0), 0xffffffffLL);
-                        again[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back(i);
+                        const int kc = nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2);
+                        if (hybrid && kc > 0) single[kc].push_back(i);   // the class streams of the large halos are busy
+                        else again[kc].push_back(i);
                     }
                 for (int k = 0; k < 3; k++) {
                     std::sort(again[k].begin(), again[k].end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
@@ -1295,18 +1371,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             bool gbuild = getenv("SOAP_ENGINE_GBUILD") == nullptr || atoi(getenv("SOAP_ENGINE_GBUILD")) != 0;
             if (gbuild) small_lists[0] = todo[0];
             else for (int k = 0; k < 3; k++) small_lists[k] = todo[k];
-            rc = launch_stage(1, small_lists, h->ev_p[1]);
-            if (rc) return rc;
             if (gbuild && (!todo[1].empty() || !todo[2].empty())) {
-                std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, tile_li, gblock_li;
+                std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, tile_li, gblock_li, sel_li;
                 for (int k = 1; k < 3; k++) rows.insert(rows.end(), todo[k].begin(), todo[k].end());
                 const size_t L = rows.size();
                 for (size_t li = 0; li < L; li++) {
-                    const long long cap = capv[rows[li]];
-                    const int nt = (int)((cap + GTILE - 1) / GTILE);
-                    const int ng = (int)std::min<long long>(GNBMAX, std::max<long long>(2, next_pow2((cap + 1023) / 1024)));
+                    // the selection holds at most est particles: tiles and bucket groups are sized by that
+                    const long long e = std::max<long long>(est[rows[li]], 1);
+                    const int nt = (int)((e + GTILE - 1) / GTILE);
+                    const int ng = (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
                     first_tile.push_back((int)tile_li.size()); ntile.push_back(nt);
                     first_gblock.push_back((int)gblock_li.size()); ngblock.push_back(ng);
+                    const int ns = (int)((e + 16383) / 16384);
+                    first_sel.push_back((int)sel_li.size()); nsel.push_back(ns);
+                    sel_li.insert(sel_li.end(), (size_t)ns, (int)li);
                     tile_li.insert(tile_li.end(), (size_t)nt, (int)li);
                     gblock_li.insert(gblock_li.end(), (size_t)ng, (int)li);
                 }
@@ -1316,7 +1394,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     h->gb_count = L + L / 4 + 16;
                     HIPCHECK(hipMalloc((void **)&h->d_gb, h->gb_count * sizeof(GBuild)));
                 }
-                const size_t nints = 5 * L + tile_li.size() + gblock_li.size();
+                const size_t nints = 7 * L + tile_li.size() + gblock_li.size() + sel_li.size();
                 if (h->gints_count < nints) {
                     if (h->d_gints) (void)hipFree(h->d_gints);
                     h->d_gints = nullptr;
@@ -1327,25 +1405,29 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
                 HIPCHECK(hipStreamWaitEvent(cs, h->ev_p[1], 0));
                 int *d = h->d_gints;
-                const std::vector<int> *parts[7] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li};
-                int *dptr[7];
-                for (int q = 0; q < 7; q++) {
+                const std::vector<int> *parts[10] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li};
+                int *dptr[10];
+                for (int q = 0; q < 10; q++) {
                     dptr[q] = d;
                     HIPCHECK(hipMemcpyAsync(d, parts[q]->data(), parts[q]->size() * sizeof(int), hipMemcpyHostToDevice, cs));
                     d += parts[q]->size();
                 }
-                P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6];
+                P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6]; P.sel_li = dptr[9];
                 HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
                 HIPCHECK(hipStreamWaitEvent(h->cls[0].stream, h->ev_p[1], 0));   // (class 0 reads the same parameter block: upload first)
                 HIPCHECK(hipEventRecord(C.pstart[0], cs));
                 soap_launch_gbuild(cs, h->d_params, h->arena, (long long)L, (long long)tile_li.size(), (long long)gblock_li.size(),
-                                   dptr[0], dptr[1], dptr[2], dptr[3], dptr[4]);
+                                   (long long)sel_li.size(), dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8]);
                 HIPCHECK(hipEventRecord(C.pdone[0], cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
                 HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
                 if (C.pms[0] == 0.0) C.pms[0] = -1.0;
                 h->n_gbuild += (long long)L;
             }
+            // (the small halos' groups are persistent and would hold all LDS if they started first: the large halos'
+            // kernels, which come and go, are enqueued before them)
+            rc = launch_stage(1, small_lists, h->ev_p[1]);
+            if (rc) return rc;
             HIPCHECK(hipEventRecord(h->ev_p[2], st));
             // stage 2: one lane per halo (records that are not freshly built are skipped)
             soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
@@ -1366,7 +1448,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     else if (state[i] == PIPE_NEED_SUPERSET && iter < 7) rest[k].push_back(i);
                     else single[k].push_back(i);
                 }
-            rc = launch_stage(2, fin, h->ev_p[3]);
+            // large halos of a run without gas / stars: two groups each, one per family of calculations (stage_b)
+            std::vector<int> fin2[3];
+            const bool split = !P.hydro && (getenv("SOAP_ENGINE_SPLIT_PROPS") == nullptr || atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) != 0);
+            for (int k = 0; k < 3; k++)
+                for (int i : fin[k]) {
+                    if (split && k > 0) { fin2[k].push_back(i | (1 << 29)); fin2[k].push_back(i | (2 << 29)); }
+                    else fin2[k].push_back(i);
+                }
+            rc = launch_stage(2, fin2, h->ev_p[3]);
             if (rc) return rc;
             HIPCHECK(hipEventRecord(h->ev_p[4], st));
             for (int k = 0; k < 3; k++) { h->n_pipeline += (long long)fin[k].size(); h->cls[k].nh += (long long)fin[k].size(); todo[k].swap(rest[k]); }
@@ -1395,43 +1485,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
-        // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
-        // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
-        // (two equal-priority user streams get distinct hardware queues, three do not).
-        const int order[3] = {2, 1, 0};
-        for (int oi = 0; oi < 3; oi++) {
-            const int k = order[oi];
-            soap_engine::Class &C = h->cls[k];
-            hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
-            if (todo[k].empty()) continue;
-            if (only_class >= 0 && k != only_class) { todo[k].clear(); continue; }   // diagnostics
-            any = true;
-            int ng = (int)std::min<long long>(groups[k], (long long)todo[k].size());
-            int nwg = ng;
-            int rc = alloc_slab(C, caps[k], groups[k]);
+        if (only_class >= 0) for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear();   // diagnostics
+        for (int k = 0; k < 3; k++) any = any || !todo[k].empty();
+        {
+            int rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
-            if (C.todo_cap < (long long)todo[k].size()) {
-                if (C.d_todo) (void)hipFree(C.d_todo);
-                C.todo_cap = std::max<long long>((long long)todo[k].size(), h->n_halo);
-                HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
+        }
+        if (pass == 0) {
+            // the large halos launched before the pipeline stages: their statuses are checked with this pass
+            for (int k = 0; k < 3; k++) {
+                if (early[k].empty()) continue;
+                any = true;
+                todo[k].insert(todo[k].end(), early[k].begin(), early[k].end());
+                HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
             }
-            HIPCHECK(hipStreamWaitEvent(cs, h->ev0, 0));
-            HIPCHECK(hipMemcpyAsync(C.d_todo, todo[k].data(), todo[k].size() * 4, hipMemcpyHostToDevice, cs));
-            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
-            const RunParams *dp = h->d_params;
-            HIPCHECK(hipEventRecord(C.start, cs));
-            C.nh += (long long)todo[k].size();
-            if (!want_inertia) {
-                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            } else {
-                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-                else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, (long long)todo[k].size());
-            }
-            HIPCHECK(hipEventRecord(C.done, cs));
-            HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         }
         if (!any) break;
         HIPCHECK(hipEventRecord(h->ev1, st));

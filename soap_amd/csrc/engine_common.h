@@ -41,6 +41,17 @@
 // ------------------------------------------------------------------------------------------
 // device-side views
 // ------------------------------------------------------------------------------------------
+// Everything the property passes need of one particle, in ONE record at its mesh-cell-ordered position: the slab
+// build fetches five 16-byte words (two cache lines) per selected particle instead of eight scattered 8-byte fields
+// from eight arrays.  For the neutrino slot vx holds the raw (unweighted) mass and m the weighted one.
+struct alignas(16) Pay {
+    double vx, vy, vz, m;
+    long long grnr, fof;
+    double x, y, z;
+    double pad_;
+};
+static_assert(sizeof(Pay) == 80, "five 16-byte words");
+
 struct TypeDev {
     long long n;
     int res;
@@ -53,6 +64,7 @@ struct TypeDev {
     const long long *fof;
     const unsigned *orig;         // original index of the particle at cell-ordered position p
     const unsigned *cell_offset;  // res^3 + 1 entries
+    const Pay *pay;               // payload records in cell order
     double pos_min[3], pos_max[3], cell_size[3];
 };
 
@@ -116,16 +128,17 @@ struct HaloHdr {
 // halo_kernel.inc): append cursor of the selection, the sample sort's splitters / bucket fills / bucket groups, and
 // the slab facts that are reduced with atomics.
 #define GTILE 4096       // slab entries per tile (one 256-thread workgroup each)
-#define GNBMAX 1024      // most buckets of the distributed sample sort
+#define GNBMAX 2048      // most buckets of the distributed sample sort
 struct GBuild {
     int row;             // halo row
     int first_tile, ntile;     // tiles covering the halo's arena slice
     int first_gblock, ngblock; // blocks of the bucket-group sort reserved for it
+    int first_sel, nsel;       // parts of the selection (whole candidate runs are dealt round-robin to them)
     unsigned n;          // particles selected (append cursor)
     int nb, ngroup, overflow;
     int q_unsorted, i_firstpos, i_lastbound, i_firstdm;
     int nbi[4];
-    int pad_;
+    int unequal;         // the masses of the slab are not all the same value
     double splitter[GNBMAX];
     unsigned bcount[GNBMAX];
     int bstart[GNBMAX + 1];
@@ -160,7 +173,7 @@ struct RunParams {
     unsigned *probe_count;
     HaloHdr *hdr;                 // pipeline path: one record per staged halo (null on the single-kernel path)
     GBuild *gb;                   // pipeline path: scratch of the large halos' tile-parallel build
-    const int *tile_li, *gblock_li;   // tile / sort block -> entry of gb
+    const int *tile_li, *gblock_li, *sel_li;   // tile / sort block / selection part -> entry of gb
 };
 
 // ------------------------------------------------------------------------------------------

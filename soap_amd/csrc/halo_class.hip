@@ -2,6 +2,7 @@
 // -DGINERTIA=0|1, -DGMODE=0|1|2 (single kernel / pipeline build stage / pipeline property stage): compiled as separate translation units so that the classes build in parallel.  Exports a plain
 // launcher per variant; engine.hip owns everything on the host side.
 #include "engine_common.h"
+#include <algorithm>
 
 #if GCLASS == 64
 // a wavefront-level "barrier": LDS and global accesses of one wave are issued in order, so only the
@@ -18,7 +19,11 @@
 #define GRP 256
 #define GNW 4
 #define GWG 256
+#if GMODE == 3
+#define GCH 2048           // the tile-parallel build sorts bucket groups of at most this many entries: less LDS, more groups per CU
+#else
 #define GCH 4096
+#endif
 #define SORT_NBMAX 256
 #define GLB 2
 #define GATTR __launch_bounds__(GRP, GLB)
@@ -62,20 +67,23 @@ namespace {
 // the whole tile-parallel build of `nlarge` large halos: ten launches on one stream, kernel boundaries are the
 // only synchronisation between the phases
 extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles,
-                                   long long ngblocks, const int *rows, const int *first_tile, const int *ntile,
-                                   const int *first_gblock, const int *ngblock) {
+                                   long long ngblocks, long long nselparts, const int *rows, const int *first_tile, const int *ntile,
+                                   const int *first_gblock, const int *ngblock, const int *first_sel, const int *nsel) {
     if (nlarge <= 0) return;
     const unsigned g64 = (unsigned)((nlarge + 63) / 64);
-    hipLaunchKernelGGL(k_ginit, dim3(g64), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock);
-    hipLaunchKernelGGL(k_gselect, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_ginit, dim3(g64), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel);
+    // fixed grids that walk their tiles / bucket groups (a workgroup per tile would cost more in dispatch than in work)
+    const unsigned gt = (unsigned)std::min<long long>(ntiles, 256 * 8),
+                   gg = (unsigned)std::min<long long>(ngblocks, 256 * 2);
+    hipLaunchKernelGGL(k_gselect, dim3((unsigned)std::min<long long>(nselparts, 256 * 2)), dim3(GRP), 0, stream, params, arena, nselparts);
     hipLaunchKernelGGL(k_gsplit, dim3((unsigned)nlarge), dim3(GRP), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_ghist, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_gscan, dim3((unsigned)nlarge), dim3(GRP), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_gscatter, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_gsortgroups, dim3((unsigned)ngblocks), dim3(GRP), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_ggather, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_ghist, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
+    hipLaunchKernelGGL(k_gscan, dim3((unsigned)nlarge), dim3(64), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gscatter, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
+    hipLaunchKernelGGL(k_gsortgroups, dim3(gg), dim3(GRP), 0, stream, params, arena, ngblocks);
+    hipLaunchKernelGGL(k_ggather, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gcumsum, dim3((unsigned)nlarge), dim3(64), 0, stream, params, arena);
-    hipLaunchKernelGGL(k_gpost, dim3((unsigned)ntiles), dim3(GRP), 0, stream, params, arena);
+    hipLaunchKernelGGL(k_gpost, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
 #else

@@ -31,7 +31,9 @@ class _NoInertia:
 
 
 def _run(engine, props, sc, halos_np, pipeline, resident=None):
-    os.environ["SOAP_ENGINE_PIPELINE"] = "1" if pipeline else "0"
+    # 0: single-kernel path; 2: every halo through the pipeline (1 / unset: the default mix, small halos through the
+    # pipeline beside the large ones on the single-kernel path)
+    os.environ["SOAP_ENGINE_PIPELINE"] = str(int(pipeline))
     try:
         ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(len(halos_np["index"]), dtype=np.int32))
         results = []
@@ -58,10 +60,15 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
     engine = halo_tasks.make_engine(sc, device=0)
     halo_tasks.stage_chunk(engine, data_np)
     ha1, res1, raw1, t1, (np1, ns1) = _run(engine, props, sc, halos_np, pipeline=False)
-    ha2, res2, raw2, t2, (np2, ns2) = _run(engine, props, sc, halos_np, pipeline=True)
+    ha2, res2, raw2, t2, (np2, ns2) = _run(engine, props, sc, halos_np, pipeline=2)
     assert np1 == 0 and np2 > 0.8 * len(halos_np["index"]), (np1, np2, ns2)
+    n_gbuild = engine.kernel_ms("n_gbuild")
+    # the mix (small halos through the pipeline beside the large ones on the single-kernel path) gives the same again
+    ha5, _, raw5, t5, (np5, ns5) = _run(engine, props, sc, halos_np, pipeline=1)
+    assert (np5 > 0 or nb_small is not None) and np.array_equal(t5, t2) and np.array_equal(raw5["stats"][:, :3], raw2["stats"][:, :3])
+    assert np.array_equal(ha5["read_radius"], ha2["read_radius"]) and np.array_equal(raw5["status"], raw2["status"])
     if nb_small is not None:
-        assert engine.kernel_ms("n_gbuild") > 0.3 * len(halos_np["index"])
+        assert n_gbuild > 0.3 * len(halos_np["index"])
     assert np.array_equal(raw1["status"], raw2["status"])
     assert np.array_equal(ha1["done"], ha2["done"])
     assert np.array_equal(ha1["read_radius"], ha2["read_radius"])
@@ -72,7 +79,7 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
         assert np.any(raw2["status"] == 1)   # this chunk has halos that need a larger read radius
         # with the box declared resident both paths finish them in the same call, again identically
         ha3, _, raw3, t3, _ = _run(engine, props, sc, halos_np, pipeline=False, resident=np.inf)
-        ha4, _, raw4, t4, (np4, ns4) = _run(engine, props, sc, halos_np, pipeline=True, resident=np.inf)
+        ha4, _, raw4, t4, (np4, ns4) = _run(engine, props, sc, halos_np, pipeline=2, resident=np.inf)
         assert np.all(ha3["done"] == 1) and np.all(ha4["done"] == 1)
         assert np.array_equal(ha3["read_radius"], ha4["read_radius"]) and np.array_equal(ha3["search_radius"], ha4["search_radius"])
         assert np.array_equal(raw3["stats"][:, :2], raw4["stats"][:, :2])
