@@ -262,6 +262,7 @@ def main():
     import __graft_entry__ as g
 
     g.build()
+    from soap_amd import layout
     from soap_amd.catalogue import gather_catalogue
     from soap_amd.core import chunk_tasks, halo_tasks
     from soap_amd.synthetic import make_chunk
@@ -304,7 +305,7 @@ def main():
         read radius (their cells are read again, chunk_tasks.py:189-367)."""
         ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
         cur, resident = region, resident0
-        stats = np.zeros((H, 4), dtype=np.int64)
+        stats = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
         status = np.full(H, -99, dtype=np.int32)
         table = state["table"]
         t_h = 0.0

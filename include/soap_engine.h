@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SOAP_ENGINE_ABI_VERSION 3
+#define SOAP_ENGINE_ABI_VERSION 4
+#define SOAP_STATS_COLUMNS 6 /* int64 per halo in the stats array of soap_engine_fetch */
 
 /* particle types the selections know about, in the reference's concatenation order
  * (SO_properties.py:3520-3550).  "slot" below is the position in this list. */
@@ -220,8 +221,10 @@ int64_t soap_engine_row_columns(const soap_engine *h);
  *   table          [n_halo][row_columns] fp64 pre-cast values (zeros where not computed)
  *   status         [n_halo]
  *   search_radius, read_radius  [n_halo] updated radii (halo_tasks.py:393-402)
- *   stats          [n_halo][4] int64: n_loop, n_sel (final sphere), n_cand (final),
- *                  shader clocks spent on the halo
+ *   stats          [n_halo][SOAP_STATS_COLUMNS] int64: n_loop of the last attempt, n_sel (final sphere),
+ *                  n_cand (final), shader clocks spent on the halo, n_loop summed over every attempt made
+ *                  inside the engine, number of those attempts (1 + restarts inside the resident radius): the
+ *                  last two are what halo_tasks.py:188-191, :411-414 add to InputHalos/n_loop and n_process
  */
 int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double *search_radius,
                           double *read_radius, int64_t *stats);

@@ -1198,13 +1198,15 @@ class RadiusMultipleSOProperties(SOProperties):
         if key not in halo_result:
             raise RuntimeError(f"Trying to obtain {key}, but it has not been calculated!")
         r32 = halo_result[key].stored[0]  # float32, comoving code length
-        # :3917  physical_radius_mpc = multiple * R.to("Mpc").value  (float64 arithmetic)
-        self._radius_comoving = self.multiple * float(r32)
+        # :3917  physical_radius_mpc = multiple * R.to("Mpc").value: a python float times a float32 value is float32
+        # (NumPy >= 2 promotion), so the radius of this SO is the FLOAT32 product -- pinned at a = 1 by
+        # tests/golden/control_flow.npz (search radius handed back by process_single_halo, SO/5xR_500_crit/SORadius);
+        # the comoving <-> physical factors around it are applied in float64 here
+        r_mult32 = np.float32(self.multiple) * np.float32(r32)
+        self._radius_comoving = float(r_mult32)
         self.physical_radius_mpc = self._radius_comoving * self.units.a / (1000.0 * self.units.kpc)
-        # :3920  `multiple * halo_result[key][0]`: python float * 0-d float32 array stays
-        # float32 (NumPy>=2 promotion); it is then compared with the float64 search radius
-        # (both 0-d arrays in the reference, so the comparison itself is in float64)
-        if float(np.float32(self.multiple) * r32) > float(search_radius):
+        # :3920  `multiple * halo_result[key][0]`: the same float32 product, compared with the float64 search radius
+        if float(r_mult32) > float(search_radius):
             raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
         super().calculate(input_halo, search_radius, data, halo_result)
 
@@ -1346,14 +1348,19 @@ class ProjectedApertureProperties:
                      "HalfMassRadiusGas", "HalfMassRadiusStar", "HalfMassRadiusBaryon",
                      *PROJECTED_INERTIA_KEYS]  # fmt: skip
 
+    # properties with a direct dependence on the aperture size (property_names, :1596-1676, value True) among the ones
+    # restated here: a copied aperture leaves them at zero when strict_halo_copy is set (:1880-1883)
+    APERTURE_DEPENDENT = tuple(k for k in PROJECTED_INERTIA_KEYS if "Noniterative" not in k)
+
     def __init__(self, units: Units, radius_kpc: float, all_radii_kpc=None,
-                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
+                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True, strict_halo_copy=False):  # fmt: skip
         self.units = units
         self.aperture_physical_radius_kpc = radius_kpc
         self.all_radii_kpc = list(all_radii_kpc) if all_radii_kpc is not None else [radius_kpc]
         self.halo_filter = halo_filter
         self.filters = filters
         self.dmo = dmo
+        self.strict_halo_copy = strict_halo_copy
         self.physical_radius_mpc = 0.001 * radius_kpc
         self.mean_density_multiple = None
         self.critical_density_multiple = None
@@ -1383,7 +1390,7 @@ class ProjectedApertureProperties:
         for proj in ("projx", "projy", "projz"):
             g = f"{self.group_name}/{proj}"
             for key in self.property_list:
-                if copied is not None:
+                if copied is not None and not (self.strict_halo_copy and key in self.APERTURE_DEPENDENT):
                     pv = halo_result[f"{copied}/{proj}/{key}"]
                     halo_result[f"{g}/{key}"] = Value(pv.raw.copy(), pv.stored.copy())
                 else:
@@ -1551,6 +1558,8 @@ def process_single_halo(mesh, data, halo_prop_list, units: Units, input_halo, ta
                 break
         search_radius = input_halo["search_radius"]
         required_radius = units.mpc_to_comoving(max_physical_radius_mpc)
+        if stats is not None:
+            stats["n_loop"] = n_loop
         if required_radius > input_halo["read_radius"]:
             input_halo["search_radius"] = max(search_radius, required_radius)
             return None

@@ -45,6 +45,14 @@ _INPUT_HALO_COLUMNS = {
 }  # fmt: skip
 
 
+# halo_tasks.py:203-227: present when the caller's halo_arrays carry them (float32 in the reference)
+_TIMING_COLUMNS = {
+    "n_loop": "Number of loops before target density was reached",
+    "n_process": "Number of times this halo was processed (a halo will have to be reprocessed if it's target density "
+                 "is not reached with the region currently loaded in memory)",
+}  # fmt: skip
+
+
 def target_density_of(halo_prop_list, cellgrid):
     """Minimum density any calculation needs (halo_tasks.py:306-317), converted once to
     mass / comoving length^3.  None if no calculation sets a density multiple."""
@@ -188,6 +196,12 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
     upd = again | ok   # finished halos carry the radii of their in-engine retries (resident_radius), if any
     halo_arrays["read_radius"][todo[upd]] = out["read_radius"][upd]
     halo_arrays["search_radius"][todo[upd]] = out["search_radius"][upd]
+    # --record-halo-timings columns (halo_centres.py:205-226): loops of the x1.2 radius search and attempts, summed
+    # over every time the halo was processed (halo_tasks.py:188-191 for the attempt that finishes, :411-414 otherwise)
+    if "n_loop" in halo_arrays:
+        halo_arrays["n_loop"][todo[upd]] += out["stats"][upd, 4].astype(halo_arrays["n_loop"].dtype)
+    if "n_process" in halo_arrays:
+        halo_arrays["n_process"][todo[upd]] += out["stats"][upd, 5].astype(halo_arrays["n_process"].dtype)
 
     if unpack:
         coloff = np.concatenate([[0], np.cumsum([engine.desc_columns(c) for c in calcs])])
@@ -205,6 +219,9 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
             i = todo[j]
             for name, (dset, dtype, desc, phys, aexp) in _INPUT_HALO_COLUMNS.items():
                 halo_result[dset] = (np.asarray(halo_arrays[name][i]).astype(dtype), desc, phys, aexp)
+            for name, desc in _TIMING_COLUMNS.items():
+                if name in halo_arrays:
+                    halo_result[f"InputHalos/{name}"] = (np.asarray(halo_arrays[name][i]), desc, True, None)
             results.append(halo_result)
 
     nr_left = int(np.sum(np.asarray(halo_arrays["done"]) == 0))

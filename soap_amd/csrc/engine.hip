@@ -723,7 +723,7 @@ static void free_halos(soap_engine *h) {
     // nine arrays cost ~0.8 ms per staging)
     const size_t n = (size_t)h->n_halo;
     std::pair<void *, size_t> ptrs[] = {{h->d_cofp, n * 24}, {h->d_search, n * 8}, {h->d_read, n * 8}, {h->d_index, n * 8},
-                                        {h->d_nrbound, n * 8}, {h->d_stats, n * 32}, {h->d_central, n * 4},
+                                        {h->d_nrbound, n * 8}, {h->d_stats, n * 8 * SOAP_STATS_COLUMNS}, {h->d_central, n * 4},
                                         {h->d_status, n * 4}, {h->d_todo, n * 4}, {h->d_resident, n * 8}};
     for (auto &p : ptrs) if (p.first) h->pool.release(p.first, p.second);
     h->d_cofp = h->d_search = h->d_read = nullptr;
@@ -956,7 +956,7 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n, const double *cofp,
     HIPCHECK(h->pool.alloc((void **)&h->d_read, (size_t)n * 8));
     HIPCHECK(h->pool.alloc((void **)&h->d_index, (size_t)n * 8));
     HIPCHECK(h->pool.alloc((void **)&h->d_nrbound, (size_t)n * 8));
-    HIPCHECK(h->pool.alloc((void **)&h->d_stats, (size_t)n * 32));
+    HIPCHECK(h->pool.alloc((void **)&h->d_stats, (size_t)n * 8 * SOAP_STATS_COLUMNS));
     HIPCHECK(h->pool.alloc((void **)&h->d_central, (size_t)n * 4));
     HIPCHECK(h->pool.alloc((void **)&h->d_status, (size_t)n * 4));
     HIPCHECK(h->pool.alloc((void **)&h->d_todo, (size_t)n * 4));
@@ -969,7 +969,7 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n, const double *cofp,
     HIPCHECK(hipMemcpyAsync(h->d_central, is_central, (size_t)n * 4, hipMemcpyHostToDevice, st));
     h->h_nrbound.assign(nr_bound_part, nr_bound_part + n);
     HIPCHECK(hipMemsetAsync(h->d_status, 0, (size_t)n * 4, st));
-    HIPCHECK(hipMemsetAsync(h->d_stats, 0, (size_t)n * 32, st));
+    HIPCHECK(hipMemsetAsync(h->d_stats, 0, (size_t)n * 8 * SOAP_STATS_COLUMNS, st));
     HIPCHECK(hipStreamSynchronize(st));
     return 0;
 }
@@ -1577,7 +1577,7 @@ int32_t soap_engine_fetch(soap_engine *h, double *table, int32_t *status, double
     if (status) HIPCHECK(hipMemcpyAsync(status, h->d_status, n * 4, hipMemcpyDeviceToHost, st));
     if (search_radius) HIPCHECK(hipMemcpyAsync(search_radius, h->d_search, n * 8, hipMemcpyDeviceToHost, st));
     if (read_radius) HIPCHECK(hipMemcpyAsync(read_radius, h->d_read, n * 8, hipMemcpyDeviceToHost, st));
-    if (stats) HIPCHECK(hipMemcpyAsync(stats, h->d_stats, n * 32, hipMemcpyDeviceToHost, st));
+    if (stats) HIPCHECK(hipMemcpyAsync(stats, h->d_stats, n * 8 * SOAP_STATS_COLUMNS, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     return 0;
 }

@@ -83,7 +83,7 @@ struct HaloDev {
     const int *is_central;
     const long long *nr_bound;
     int *status;
-    long long *stats;  // [n][4]
+    long long *stats;  // [n][SOAP_STATS_COLUMNS]
     const int *todo;   // optional list of rows to process (retry pass), or null
     long long n_todo;
     const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
@@ -118,7 +118,7 @@ struct HaloHdr {
     // ---- written by the radius loop
     int status;
     int n_final;            // particles in the final search sphere
-    long long n_loop;
+    long long n_loop, n_loop_all;
     double R_final, R_search, R_read, R_need;
     int cs_state[MAXCALC], cs_n[MAXCALC];
     double cs_R[MAXCALC], cs_M[MAXCALC];

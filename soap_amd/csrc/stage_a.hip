@@ -53,13 +53,11 @@ SOAP_DEV int so_eval(const SlabView &S, const soap_calc_desc &cd, double Rcur, i
     double R_phys = 0.0;
     if (cd.kind == SOAP_CALC_SO_MULTIPLE) {
         // parent radius as stored (float32); zero if the parent SO does not exist
+        // the FLOAT32 product multiple * R is the radius of this SO (SO_properties.py:3917-3920; see so_eval_lane)
         const float r32 = (float)parent_R;
-        R_phys = cd.radius * (double)r32;
-        // halo_prop.physical_radius_mpc = multiple * R.to("Mpc"); the scheduler converts it back
-        // (SO_properties.py:3917, halo_tasks.py:168): same two roundings as the oracle
+        R_phys = (double)((float)cd.radius * r32);
         *required = ((R_phys * a) / mpc) * mpc / a;
-        const float chk = (float)cd.radius * r32;
-        if ((double)chk > Rcur) return RES_TOO_SMALL;
+        if (R_phys > Rcur) return RES_TOO_SMALL;
     } else if (cd.kind == SOAP_CALC_SO_PHYSICAL) {
         R_phys = cd.radius;
     }
@@ -188,11 +186,11 @@ __global__ void __launch_bounds__(SA_BLK) k_stage_a(const RunParams *Pp, SlabDev
     unsigned long long done = 0ull, cached = 0ull;
     double Rcur = Rsearch;
     int status = SOAP_HALO_OK, n_restart = 0, n_final = 0;
-    long long n_loop = 0;
+    long long n_loop = 0, n_loop_all = 0;
     int pipe = PIPE_DONE;
     double R_need = 0.0;
     while (true) {
-        n_loop++;
+        n_loop++; n_loop_all++;
         if (!(Rcur <= Rread)) { status = SOAP_HALO_FATAL_RADIUS_ASSERT; break; }
         if (Rcur > R_have) { pipe = PIPE_NEED_SUPERSET; R_need = Rcur; break; }   // the build stage has to reach further
         const int n = (Rcur == R_have) ? n_have : count_le(S.q, n_have, Rcur * Rcur);
@@ -308,6 +306,7 @@ __global__ void __launch_bounds__(SA_BLK) k_stage_a(const RunParams *Pp, SlabDev
     H.status = status;
     H.n_final = n_final;
     H.n_loop = n_loop;
+    H.n_loop_all = n_loop_all;
     H.R_final = Rcur;
     H.n_restart = n_restart;
     H.R_search = Rsearch;

@@ -13,6 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CalcDesc, EngineConfig
+from .layout import STATS_COLUMNS
 
 STATUS_OK = 0
 STATUS_NEED_LARGER_READ_RADIUS = 1
@@ -238,7 +239,7 @@ class Engine:
         status = np.zeros(n, dtype=np.int32)
         search = np.zeros(n, dtype=np.float64)
         read = np.zeros(n, dtype=np.float64)
-        stats = np.zeros((n, 4), dtype=np.int64)
+        stats = np.zeros((n, STATS_COLUMNS), dtype=np.int64)
         if n > 0:
             self._check(
                 self._lib.soap_engine_fetch(
@@ -252,7 +253,7 @@ class Engine:
         status = np.zeros(n, dtype=np.int32)
         search = np.zeros(n, dtype=np.float64)
         read = np.zeros(n, dtype=np.float64)
-        stats = np.zeros((n, 4), dtype=np.int64)
+        stats = np.zeros((n, STATS_COLUMNS), dtype=np.int64)
         if n > 0:
             self._check(
                 self._lib.soap_engine_fetch(

@@ -18,6 +18,7 @@ CALC_FLAG_DM_FLOW = 1
 CALC_FLAG_ROTATION = 2
 CALC_FLAG_INERTIA = 4
 CALC_FLAG_STRICT_COPY = 8
+STATS_COLUMNS = 6   # SOAP_STATS_COLUMNS
 
 # total / dark matter / gas / stellar inertia tensors, in column order
 INERTIA_KEYS = (

@@ -47,6 +47,10 @@ class Unit(float):
     def __pow__(self, p):
         return Unit(float(self) ** p)
 
+    def to(self, *a, **k):
+        # number * unit is a quantity in unyt; here it is still this float: converting it hands back a quantity
+        return unyt_array(float(self))
+
 
 class unyt_array(np.ndarray):
     def __new__(cls, value, units=None, dtype=None, registry=None, **kw):

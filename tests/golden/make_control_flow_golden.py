@@ -1,0 +1,356 @@
+#!/usr/bin/env python
+"""
+Golden vectors for the CONTROL-FLOW layer of the hot path, produced by the reference's own code:
+
+  SOAP/core/shared_mesh.py        SharedMesh.__init__ (run with a one-rank communicator stand-in) and
+                                  SharedMesh.query_radius_periodic  -- index sets, incl. periodic copies, resolutions 1..32
+  SOAP/core/halo_tasks.py         process_single_halo: the x1.2 radius loop, the enclosed-density test, gather + wrap, the
+                                  calculation list with done flags, the read-radius verdict, InputHalos/* columns
+  SOAP/particle_selection/*.py    SubhaloProperties / SOProperties / RadiusMultipleSOProperties / Inclusive- and
+                                  ExclusiveSphereProperties / ProjectedApertureProperties .calculate(): zero fill, category
+                                  filters, satellites, the skip / copy rule (incl. skip_gt_enclose_radius and
+                                  strict_halo_copy), the search-radius checks, type="physical"
+
+Runs ONLY in the build container (imports /root/reference, which never travels) under the unit-less `unyt` stand-in of
+tests/golden/_shims (see make_golden.py): every unit is the number 1 except kpc = 1e-3 of the length unit, so the
+fixtures use a = 1 -- the comoving <-> physical factors are NOT exercised by these vectors.  What is committed is data
+only: inputs and the reference's outputs (tests/golden/control_flow.npz).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import make_golden as mg  # noqa: E402  (stubs, DS, U)
+
+
+class OneRankComm:
+    """mpi4py communicator stand-in for SharedMesh.__init__: one rank, collectives are copies."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+    def Allreduce(self, send, recv, op=None):
+        recv[...] = send
+
+    def Reduce(self, send, recv, op=None, root=0):
+        recv[...] = send
+
+    def barrier(self):
+        pass
+
+
+class PlainSharedArray:
+    """shared_array.SharedArray stand-in: an ordinary array with .full / .local views."""
+
+    def __init__(self, shape, dtype, comm, units=None):
+        import unyt
+
+        self.full = unyt.unyt_array(np.zeros(shape, dtype=dtype))
+        self.local = self.full
+
+    def sync(self):
+        pass
+
+    def free(self):
+        pass
+
+
+def wrap_shared(arr):
+    s = PlainSharedArray.__new__(PlainSharedArray)
+    s.full = mg.U(arr)
+    s.local = s.full
+    return s
+
+
+def parallel_sort_stand_in(arr, comm=None, return_index=False):
+    idx = np.argsort(np.asarray(arr), kind="stable")
+    arr[...] = np.asarray(arr)[idx]
+    return idx if return_index else None
+
+
+# in-scope properties per class (the reference's internal keys): what oracle/halo_oracle.py restates
+IN_SCOPE = {
+    "SubhaloProperties": ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Ldm",
+                          "Vmax_unsoft", "Vmax_soft", "R_vmax_unsoft", "spin_parameter", "HalfMassRadiusTot", "HalfMassRadiusDM",
+                          "veldisp_matrix_dm", "EncloseRadius"],
+    "SOProperties": ["r", "Mtot", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Vmax_soft", "R_vmax_soft", "Mfrac_satellites",
+                     "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical", "spin_parameter", "concentration_unsoft",
+                     "concentration_soft", "DarkMatterMassFlowRate"],
+    "ApertureProperties": ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Ldm",
+                           "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft"],
+    "ProjectedApertureProperties": ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom",
+                                    "HalfMassRadiusDM", "proj_veldisp_dm", "ProjectedTotalInertiaTensor",
+                                    "ProjectedTotalInertiaTensorReduced", "ProjectedTotalInertiaTensorNoniterative",
+                                    "ProjectedTotalInertiaTensorReducedNoniterative"],
+}  # fmt: skip
+
+
+class Parameters:
+    """ParameterFile stand-in (core/parameter_file.py:85-154, :332-338)."""
+
+    record_property_timings = False
+
+    def __init__(self, table, strict=False):
+        self.names = {cls: {table[k].name for k in keys} for cls, keys in IN_SCOPE.items()}
+        self.strict = strict
+
+    def get_property_filters(self, base_halo_type, names):
+        return {n: ("basic" if n in self.names[base_halo_type] else False) for n in names}
+
+    def get_particle_property(self, partprop):
+        return tuple(partprop.split("/"))
+
+    def strict_halo_copy(self):
+        return self.strict
+
+
+def main():
+    mg._install_stubs()
+    import unyt
+
+    from SOAP.core import halo_tasks as ref_tasks
+    from SOAP.core import shared_mesh as ref_mesh
+    from SOAP.core.category_filter import CategoryFilter
+    from SOAP.particle_selection import SO_properties as SO
+    from SOAP.particle_selection import aperture_properties as AP
+    from SOAP.particle_selection import projected_aperture_properties as PJ
+    from SOAP.particle_selection import subhalo_properties as SH
+    from SOAP.property_table import PropertyTable
+
+    class UnytWithQuantityUnits:
+        """halo_tasks.py:56,168 multiplies a NumPy scalar by unyt.Unit("swift_mpc") and converts the product: the unit has
+        to be a quantity of value 1 there (a float subclass would be swallowed by numpy.float64.__mul__)."""
+
+        @staticmethod
+        def Unit(name, registry=None):
+            return unyt.unyt_array(1.0)
+
+        def __getattr__(self, name):
+            return getattr(unyt, name)
+
+    ref_tasks.unyt = UnytWithQuantityUnits()
+    ref_mesh.shared_array.SharedArray = PlainSharedArray
+    ref_mesh.ps.parallel_sort = parallel_sort_stand_in
+    ref_mesh.MPI.MIN = "min"
+    ref_mesh.MPI.MAX = "max"
+    ref_mesh.MPI.SUM = "sum"
+    comm = OneRankComm()
+    out = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    # 1. SharedMesh: build + ball queries (tests/test_shared_mesh.py:76-124 cases: box-filling, sub-region, wrapped,
+    #    one particle; resolutions 1..32)
+    # ------------------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(20240)
+    L = 100.0
+    mesh_cases = []
+    for res, n, lo, hi in ((1, 400, 0.0, 100.0), (2, 1500, 0.0, 100.0), (5, 3000, 30.0, 60.0), (13, 5000, 0.0, 100.0),
+                           (32, 8000, 0.0, 100.0), (8, 1, 10.0, 11.0), (4, 2500, -20.0, 35.0)):
+        pos = rng.uniform(lo, hi, (n, 3))
+        if res == 13:
+            pos[:50] = pos[0]   # many particles on one spot
+        m = ref_mesh.SharedMesh(comm, wrap_shared(pos), res)
+        case = dict(res=np.array(res), pos=pos, pos_min=np.asarray(m.pos_min, dtype=float), pos_max=np.asarray(m.pos_max, dtype=float),
+                    cell_size=np.asarray(m.cell_size, dtype=float), cell_count=np.asarray(m.cell_count.full),
+                    cell_offset=np.asarray(m.cell_offset.full))
+        queries = []
+        for q in range(14):
+            centre = rng.uniform(0.0, L, 3)
+            radius = float(rng.choice([0.0, 0.5, 3.0, 12.0, 30.0, 49.0, 75.0]))
+            if q == 0:
+                centre = pos[0].copy() % L
+            if q == 1:
+                centre = np.array([99.5, 0.2, 50.0])   # the sphere crosses two faces of the box
+            idx = m.query_radius_periodic(mg.U(centre), radius, wrap_shared(pos), L)
+            queries.append((centre, radius, np.sort(np.asarray(idx)).astype(np.int64)))
+        case["q_centre"] = np.array([q[0] for q in queries])
+        case["q_radius"] = np.array([q[1] for q in queries])
+        case["q_count"] = np.array([len(q[2]) for q in queries])
+        case["q_index"] = np.concatenate([q[2] for q in queries]) if queries else np.zeros(0, dtype=np.int64)
+        mesh_cases.append(case)
+    for i, c in enumerate(mesh_cases):
+        for k, v in c.items():
+            out[f"mesh{i}|{k}"] = v
+    out["mesh|n"] = np.array(len(mesh_cases))
+    out["mesh|boxsize"] = np.array(L)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # 2. process_single_halo + the calculate() methods on small periodic boxes: one dark-matter-only, one with gas,
+    #    stars and black holes
+    # ------------------------------------------------------------------------------------------------------------
+    import dataclasses
+
+    from soap_amd.synthetic import make_chunk, to_numpy
+    from soap_amd.units import SnapshotScalars
+
+    from oracle import halo_oracle as ho   # only for the LIST of property keys the oracle restates
+
+    sc0 = dataclasses.replace(SnapshotScalars(), a=1.0, boxsize=40.0)
+    kpc = 1.0e-3
+    G = float(unyt.Unit("newton_G"))
+    scal = dict(boxsize=sc0.boxsize, critical_density=sc0.critical_density, mean_density=sc0.mean_density, G=G, kpc=kpc,
+                softening=0.0114, virBN98=sc0.virBN98, H=sc0.H, Omega_g=sc0.Omega_g, Omega_m=sc0.Omega_m)
+    for k, v in scal.items():
+        out[f"scalars|{k}"] = np.array(v)
+
+    class CellGrid:
+        snap_unit_registry = None
+        a_unit = unyt.Unit(1.0)
+        a = 1.0
+        z = 0.0
+        observer_position = mg.U(np.zeros(3))
+        snapshot_datasets = mg.DS
+
+        def __init__(self):
+            self.critical_density = mg.U(scal["critical_density"])
+            self.mean_density = mg.U(scal["mean_density"])
+            self.boxsize = mg.U(scal["boxsize"])
+            self.virBN98 = scal["virBN98"]
+            s = mg.U(scal["softening"])
+            self.baryon_softening = self.dark_matter_softening = self.nu_softening = s
+            self.cosmology = {"Omega_nu_0": 0.0, "H0 [internal units]": 1.0, "H [internal units]": scal["H"],
+                              "Omega_g": scal["Omega_g"], "Omega_m": scal["Omega_m"]}
+
+        def get_unit(self, name):
+            return unyt.Unit(1.0)
+
+    cellgrid = CellGrid()
+    table = PropertyTable.full_property_list
+    # hydro runs: every key the oracle restates that the reference class has too
+    hydro_scope = {
+        "SubhaloProperties": [k for k in ho.SubhaloProperties.property_list if k in SH.SubhaloProperties.property_list],
+        "SOProperties": [k for k in ho.SOProperties.property_list if k in SO.SOProperties.property_list
+                         and k not in ("Nnu", "Mnu", "MnuNS")],
+        "ApertureProperties": [k for k in ho.ApertureProperties.property_list if k in AP.ApertureProperties.property_list],
+        "ProjectedApertureProperties": [k for k in ho.ProjectedApertureProperties.property_list
+                                        if k in PJ.ProjectedApertureProperties.property_list],
+    }
+
+    boxes = {}
+    sc, data_t, halos_t = make_chunk(30000, 26, seed=77, scalars=sc0, satellite_fraction=0.15, read_radius_factor=2.5, nmin=25)
+    data, halos = to_numpy(data_t, halos_t)
+    halos = {k: v.copy() for k, v in halos.items()}
+    halos["read_radius"][4] = halos["search_radius"][4] * 1.3          # too small for 5xR500 / the low-density SOs
+    halos["nr_bound_part"][5] += 7                                      # catalogue disagrees: never enough bound particles
+    boxes["dmo"] = (data, halos)
+    sc, data_t, halos_t = make_chunk(24000, 14, seed=78, scalars=sc0, hydro=True, satellite_fraction=0.15, read_radius_factor=8.0,
+                                     nmin=40)
+    boxes["hydro"] = to_numpy(data_t, halos_t)
+    for bname, (bdata, bhalos) in boxes.items():
+        for pt, d in bdata.items():
+            for k, v in d.items():
+                out[f"box_{bname}|PartType{pt}|{k}"] = v
+        for k, v in bhalos.items():
+            out[f"halos_{bname}|{k}"] = v
+
+    from soap_amd import compute_halo_properties as chp
+    from tests import control_flow_cases as cases
+
+    for vname, (bname, dmo, strict, skip_incl) in cases.VARIANTS.items():
+        bdata, halos = boxes[bname]
+        params = Parameters(table, strict=strict)
+        if not dmo:
+            params.names = {cls: {table[k].name for k in keys} for cls, keys in hydro_scope.items()}
+        cf = CategoryFilter(cases.FILTERS, dmo=dmo)
+        # get_do_calculation's default dictionary (category_filter.py:69-71) is shared by every call in the process and a
+        # DMO filter writes zero gas / star / black hole numbers into it: a production run has ONE filter per process,
+        # so each variant starts from the empty dictionary here too
+        CategoryFilter.get_do_calculation.__defaults__[0].clear()
+        # the REFERENCE's classes, put in a list by the same routine (and from the same dictionaries) as the tests use for
+        # the oracle's and the engine's (compute_halo_properties.py:263-297, :339-400, :451-489 order)
+        classes = dict(
+            subhalo=lambda: SH.SubhaloProperties(cellgrid, params, None, None, cf),
+            so=lambda filt, val, typ: SO.SOProperties(cellgrid, params, None, cf, filt, val, typ),
+            so_multiple=lambda filt, val, mult, typ: SO.RadiusMultipleSOProperties(cellgrid, params, None, cf, filt, val, mult, typ),
+            inclusive=lambda filt, r, radii: AP.InclusiveSphereProperties(cellgrid, params, r, None, None, None, None, cf, filt, radii),
+            exclusive=lambda filt, r, radii: AP.ExclusiveSphereProperties(cellgrid, params, r, None, None, None, None, cf, filt, radii),
+            projected=lambda filt, r, radii: PJ.ProjectedApertureProperties(cellgrid, params, r, None, cf, filt, radii),
+        )
+        so_vars, ap_vars, pj_vars = cases.variations(dmo, skip_incl)
+        props = chp.build_halo_prop_list(None, None, so_vars, ap_vars, classes=classes, projected_vars=pj_vars)
+        out[f"{vname}|calc_names"] = np.array([p.name for p in props])
+        out[f"{vname}|box"] = np.array(bname)
+        out[f"{vname}|dmo"] = np.array(dmo)
+        out[f"{vname}|strict_halo_copy"] = np.array(strict)
+        out[f"{vname}|inclusive_skip"] = np.array(skip_incl)
+
+        udata, mesh = {}, {}
+        for pt, d in bdata.items():
+            # black holes carry DynamicalMasses in the snapshot (snapshot_datasets / mass_dataset of the reference)
+            udata[f"PartType{pt}"] = {("DynamicalMasses" if (pt == 5 and k == "Masses") else k): wrap_shared(v) for k, v in d.items()}
+            mesh[f"PartType{pt}"] = ref_mesh.SharedMesh(comm, udata[f"PartType{pt}"]["Coordinates"], cases.MESH_RESOLUTION)
+        out[f"{vname}|mesh_resolution"] = np.array(cases.MESH_RESOLUTION)
+        # halo_tasks.py:306-317
+        target_density = None
+        for hp in props:
+            for mult, rho in ((hp.mean_density_multiple, scal["mean_density"]), (hp.critical_density_multiple, scal["critical_density"])):
+                if mult is not None:
+                    d = mult * rho
+                    target_density = d if target_density is None or d < target_density else target_density
+        out[f"{vname}|target_density"] = np.array(target_density)
+        nh = len(halos["index"])
+        for i in range(nh):
+            # the halo's row of halo_arrays, carried from one attempt to the next as process_halos does
+            # (halo_tasks.py:366-414: read_radius <- max(1.5 read_radius, search_radius); n_loop / n_process accumulate)
+            row = {"search_radius": float(halos["search_radius"][i]), "read_radius": float(halos["read_radius"][i]), "n_loop": 0.0,
+                   "n_process": 0.0}
+            tag = f"{vname}|halo{i:02d}"
+            attempts = []
+            result = None
+            raised = None
+            for attempt in range(10):
+                input_halo = {
+                    "cofp": mg.U(halos["cofp"][i].copy()), "index": mg.U(halos["index"][i]), "is_central": mg.U(halos["is_central"][i]),
+                    "nr_bound_part": mg.U(halos["nr_bound_part"][i]), "search_radius": mg.U(row["search_radius"]),
+                    "read_radius": mg.U(row["read_radius"]), "n_loop": mg.U(row["n_loop"]), "n_process": mg.U(row["n_process"]),
+                }
+                td = mg.U(target_density) if halos["is_central"][i] == 1 else None
+                try:
+                    result, timings = ref_tasks.process_single_halo(mesh, None, udata, props, cellgrid.critical_density,
+                                                                    cellgrid.mean_density, cellgrid.boxsize, input_halo, td)
+                except AttributeError as err:
+                    # SO_properties.py:457: a radius-multiple SO whose parent radius is 0 has neither a density nor a
+                    # physical radius and the reference stops with "no attribute 'SO_r'": no behaviour to match there
+                    if "SO_r" not in str(err):
+                        raise
+                    raised = str(err)
+                    break
+                n_loop = float(timings["n_loop"]) if result is None else float(result["InputHalos/n_loop"][0]) - row["n_loop"]
+                attempts.append((row["search_radius"], row["read_radius"], n_loop, float(result is not None),
+                                 float(input_halo["search_radius"])))
+                if result is not None:
+                    break
+                row["read_radius"] = float(max(input_halo["read_radius"] * ref_tasks.READ_RADIUS_FACTOR, input_halo["search_radius"]))
+                row["search_radius"] = float(input_halo["search_radius"])
+                row["n_loop"] += timings["n_loop"]
+                row["n_process"] += timings["n_process"]
+            # columns: search radius in, read radius in, n_loop of this attempt, done, search radius out
+            out[f"{tag}|attempts"] = np.array(attempts).reshape(-1, 5)
+            if raised is not None:
+                out[f"{tag}|reference_raised"] = np.array(raised)
+                continue
+            out[f"{tag}|done"] = np.array(result is not None)
+            if result is None:
+                continue
+            # one packed record per halo: names, lengths, and the values as float64 (counts and flags are exact in it)
+            keys = sorted(k for k in result if "_time" not in k)
+            vals = [np.atleast_1d(np.asarray(result[k][0])).astype(np.float64).ravel() for k in keys]
+            out[f"{tag}|keys"] = np.array(keys)
+            out[f"{tag}|sizes"] = np.array([len(v) for v in vals])
+            out[f"{tag}|values"] = np.concatenate(vals)
+            out[f"{tag}|float32"] = np.array([np.asarray(result[k][0]).dtype == np.float32 for k in keys])
+    np.savez_compressed(os.path.join(HERE, "control_flow.npz"), **out)
+    print("control-flow golden vectors written:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

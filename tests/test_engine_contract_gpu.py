@@ -177,7 +177,7 @@ def test_resident_radius_replaces_the_retry_passes(built_library):
     # (a) the reference's way: call again until nothing is left
     ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
     table_a = np.zeros((H, 0))
-    stats_a = np.zeros((H, 4), dtype=np.int64)
+    stats_a = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
     ncall = 0
     while np.any(ha["done"] == 0) and ncall < 12:
         out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
