@@ -108,11 +108,27 @@ enum {
                                       tensor family over the particles of the search sphere */
     SOAP_CALC_FLAG_ROTATION = 2,   /* gas / star / baryon kappa_corot and disc-to-total fractions are wanted
                                       (kinematic_properties.py:266-425): one more pass over the selection */
+    SOAP_CALC_FLAG_PROPERTY_RADIUS = 16, /* APERTURE_INCL / APERTURE_EXCL whose radius is a multiple of a property of the
+                                      bound subhalo (aperture_properties.py:3973-3981, :4131-4138;
+                                      compute_halo_properties.py:403-440): `radius` holds the multiple, `parent` the
+                                      property (SOAP_RADIUS_*), physical_radius_mpc is 0 and no copy rule applies */
     SOAP_CALC_FLAG_STRICT_COPY = 8 /* parameters.strict_halo_copy(): an aperture that repeats the next-smaller one
                                       (EncloseRadius rule) leaves the properties that depend on the aperture size
                                       itself at zero instead of copying them (aperture_properties.py:4117-4120,
                                       projected_aperture_properties.py:1880-1883).  Of the properties this engine
                                       emits those are the iterative 2D inertia tensors of projected apertures */
+};
+
+/* soap_calc_desc.parent of a calculation with SOAP_CALC_FLAG_PROPERTY_RADIUS: the BoundSubhalo property, as stored
+ * (float32), that is multiplied by `radius` */
+enum {
+    SOAP_RADIUS_HALF_MASS_TOTAL = 0,   /* BoundSubhalo/HalfMassRadiusTotal */
+    SOAP_RADIUS_HALF_MASS_DM = 1,      /* BoundSubhalo/HalfMassRadiusDarkMatter */
+    SOAP_RADIUS_HALF_MASS_GAS = 2,     /* BoundSubhalo/HalfMassRadiusGas */
+    SOAP_RADIUS_HALF_MASS_STARS = 3,   /* BoundSubhalo/HalfMassRadiusStars */
+    SOAP_RADIUS_HALF_MASS_BARYONS = 4, /* BoundSubhalo/HalfMassRadiusBaryons */
+    SOAP_RADIUS_ENCLOSE = 5,           /* BoundSubhalo/EncloseRadius */
+    SOAP_RADIUS_NPROPS = 6
 };
 
 /* per-halo status column */

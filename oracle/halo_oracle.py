@@ -1226,19 +1226,35 @@ class ApertureProperties:
         "kappa_corot_gas", "kappa_corot_star", "kappa_corot_baryons", "DtoTgas", "DtoTstar",
     ]  # fmt: skip
 
-    def __init__(self, units: Units, radius_kpc: float, inclusive: bool, all_radii_kpc=None,
-                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True):  # fmt: skip
+    # output name -> key of the bound-subhalo properties an aperture radius can be a multiple of
+    RADIUS_PROPERTY_KEYS = {
+        "HalfMassRadiusTotal": "HalfMassRadiusTot", "HalfMassRadiusDarkMatter": "HalfMassRadiusDM",
+        "HalfMassRadiusGas": "HalfMassRadiusGas", "HalfMassRadiusStars": "HalfMassRadiusStar",
+        "HalfMassRadiusBaryons": "HalfMassRadiusBaryon", "EncloseRadius": "EncloseRadius",
+    }  # fmt: skip
+
+    def __init__(self, units: Units, radius_kpc: Optional[float], inclusive: bool, all_radii_kpc=None,
+                 halo_filter="basic", filters=DEFAULT_FILTERS, dmo=True, aperture_property=None):  # fmt: skip
+        """aperture_property = ("BoundSubhalo/<output name>", multiple) instead of radius_kpc: aperture_properties.py:3973-3981"""
         self.units = units
         self.aperture_physical_radius_kpc = radius_kpc
+        self.aperture_property = aperture_property
         self.inclusive = inclusive
         self.all_radii_kpc = list(all_radii_kpc) if all_radii_kpc is not None else [radius_kpc]
         self.halo_filter = halo_filter
         self.filters = filters
         self.dmo = dmo
-        self.physical_radius_mpc = 0.001 * radius_kpc
         self.mean_density_multiple = None
         self.critical_density_multiple = None
-        aperture_name = f"{1000*radius_kpc:.0f}pc" if radius_kpc < 1 else f"{radius_kpc:.0f}kpc"
+        if radius_kpc is not None:
+            self.physical_radius_mpc = 0.001 * radius_kpc
+            aperture_name = f"{1000*radius_kpc:.0f}pc" if radius_kpc < 1 else f"{radius_kpc:.0f}kpc"
+        else:
+            prop = aperture_property[0].split("/")[-1]
+            assert aperture_property[0].split("/")[0] == "BoundSubhalo"
+            aperture_name = prop if aperture_property[1] == 1 else f"{int(aperture_property[1])}x{prop}"
+            self.physical_radius_mpc = 0
+            self._radius_key = f"BoundSubhalo/{self.RADIUS_PROPERTY_KEYS[prop]}"
         if inclusive:
             self.name = f"inclusive_sphere_{aperture_name}"
             self.group_name = f"InclusiveSphere/{aperture_name}"
@@ -1254,7 +1270,7 @@ class ApertureProperties:
         copied = None
         skip = False
         # skip/copy rule (aperture_properties.py:4082-4123)
-        i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc)
+        i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc) if self.aperture_property is None else 0
         if i_radius != 0 and ("BoundSubhalo/EncloseRadius" in halo_result):
             r_enclose = float(halo_result["BoundSubhalo/EncloseRadius"].stored[0])  # float32
             r_previous_kpc = self.all_radii_kpc[i_radius - 1]
@@ -1265,7 +1281,14 @@ class ApertureProperties:
                             else f"{r_previous_kpc:.0f}kpc")  # fmt: skip
                     copied = f"ExclusiveSphere/{prev}"
         if do_calc[self.halo_filter] and not skip:
-            aperture_radius = u.kpc_to_comoving(self.aperture_physical_radius_kpc)
+            if self.aperture_property is None:
+                aperture_radius = u.kpc_to_comoving(self.aperture_physical_radius_kpc)
+            else:
+                # :4131-4138  multiple * halo_result[property][0]: a python number times the stored float32 value is a
+                # float32 product (NumPy >= 2); both sides of the comparisons below are comoving lengths
+                if self._radius_key not in halo_result:
+                    raise RuntimeError(f"{self.aperture_property[0]} must be enabled if you want to use it to define an aperture")
+                aperture_radius = float(np.float32(self.aperture_property[1]) * halo_result[self._radius_key].stored[0])
             if search_radius < aperture_radius:
                 raise SearchRadiusTooSmallError("Search radius is smaller than aperture")
             out = self._calculate(input_halo, aperture_radius, data)

@@ -59,6 +59,10 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
                 cellgrid, parameters, r, None, None, None, None, category_filter, filt, radii),
             exclusive=lambda filt, r, radii: aperture_properties.ExclusiveSphereProperties(
                 cellgrid, parameters, r, None, None, None, None, category_filter, filt, radii),
+            inclusive_property=lambda filt, prop: aperture_properties.InclusiveSphereProperties(
+                cellgrid, parameters, None, prop, None, None, None, category_filter, filt, []),
+            exclusive_property=lambda filt, prop: aperture_properties.ExclusiveSphereProperties(
+                cellgrid, parameters, None, prop, None, None, None, category_filter, filt, []),
             projected=lambda filt, r, radii: projected_aperture_properties.ProjectedApertureProperties(
                 cellgrid, parameters, r, None, category_filter, filt, radii),
         )  # fmt: skip
@@ -76,9 +80,12 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
                 v.get("filter", "basic"), v["value"], v["radius_multiple"], v["type"]))  # fmt: skip
     # apertures sorted by radius (compute_halo_properties.py:339-400)
     aperture_vars = dict(sorted(aperture_vars.items(), key=lambda x: x[1].get("radius_in_kpc", 0)))
-    inclusive_radii_kpc = [v["radius_in_kpc"] for v in aperture_vars.values() if v["inclusive"]]
-    exclusive_radii_kpc = [v["radius_in_kpc"] for v in aperture_vars.values() if not v["inclusive"]]
+    inclusive_radii_kpc = [v["radius_in_kpc"] for v in aperture_vars.values() if v["inclusive"] and "radius_in_kpc" in v]
+    exclusive_radii_kpc = [v["radius_in_kpc"] for v in aperture_vars.values() if not v["inclusive"] and "radius_in_kpc" in v]
     for v in aperture_vars.values():
+        if "radius_in_kpc" not in v:
+            continue
+        assert "property" not in v and "radius_multiple" not in v
         if v["inclusive"]:
             radii_kpc = [v["radius_in_kpc"]]
             if v.get("skip_gt_enclose_radius", False):
@@ -86,6 +93,15 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
             halo_prop_list.append(classes["inclusive"](v.get("filter", "basic"), v["radius_in_kpc"], radii_kpc))
         else:
             halo_prop_list.append(classes["exclusive"](v.get("filter", "basic"), v["radius_in_kpc"], exclusive_radii_kpc))
+    # apertures whose radius is a multiple of a bound-subhalo property (compute_halo_properties.py:403-440)
+    for v in aperture_vars.values():
+        if "radius_in_kpc" in v:
+            continue
+        assert "property" in v
+        radius_multiple = v.get("radius_multiple", 1)
+        assert int(radius_multiple) == radius_multiple   # swiftsimio could not handle the group names otherwise
+        cls = classes["inclusive_property" if v["inclusive"] else "exclusive_property"]
+        halo_prop_list.append(cls(v.get("filter", "basic"), (v["property"], radius_multiple)))
     # projected apertures sorted by radius (compute_halo_properties.py:451-489)
     projected_vars = {} if projected_vars is None else projected_vars
     projected_vars = dict(sorted(projected_vars.items(), key=lambda x: x[1].get("radius_in_kpc", 0)))

@@ -1037,7 +1037,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipSetDevice(h->cfg.device));
     std::vector<int> coloff(n_calcs);
     long long ncols = 0;
-    bool want_inertia = false;
+    bool want_inertia = false, want_property_radius = false;
     for (int c = 0; c < n_calcs; c++) want_inertia = want_inertia || (calcs[c].flags & SOAP_CALC_FLAG_INERTIA);
     for (int c = 0; c < n_calcs; c++) {
         int nc = soap_engine_desc_columns(&calcs[c]);
@@ -1048,7 +1048,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (p < 1 || p >= c || calcs[p].kind < SOAP_CALC_SO_DENSITY || calcs[p].kind > SOAP_CALC_SO_MULTIPLE)
                 return fail(-7, "SO radius multiple needs an earlier SO as parent (SO_properties.py:3912-3916)");
         }
-        if ((calcs[c].kind == SOAP_CALC_APERTURE_EXCL || calcs[c].kind == SOAP_CALC_APERTURE_INCL || calcs[c].kind == SOAP_CALC_PROJECTED) && calcs[c].parent >= 0) {
+        if (calcs[c].flags & SOAP_CALC_FLAG_PROPERTY_RADIUS) {
+            if (calcs[c].kind != SOAP_CALC_APERTURE_EXCL && calcs[c].kind != SOAP_CALC_APERTURE_INCL)
+                return fail(-9, "only spherical apertures can be defined by a bound-subhalo property (aperture_properties.py:3973-3981)");
+            if (calcs[c].parent < 0 || calcs[c].parent >= SOAP_RADIUS_NPROPS)
+                return fail(-9, "unknown bound-subhalo property for an aperture radius (SOAP_RADIUS_*)");
+            want_property_radius = true;
+        } else if ((calcs[c].kind == SOAP_CALC_APERTURE_EXCL || calcs[c].kind == SOAP_CALC_APERTURE_INCL || calcs[c].kind == SOAP_CALC_PROJECTED) && calcs[c].parent >= 0) {
             int p = calcs[c].parent;
             if (p < 1 || p >= c || calcs[p].kind != calcs[c].kind) return fail(-8, "aperture parent must be an earlier aperture of the same kind");
         }
@@ -1231,7 +1237,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         return 0;
     };
-    bool pipeline = !want_inertia && !P.has_nu && !P.literal;
+    bool pipeline = !want_inertia && !P.has_nu && !P.literal && !want_property_radius;
     // SOAP_ENGINE_PIPELINE: unset / 0 the single-kernel path (the fastest on the reference configurations so far, DESIGN.md
     // section 5.3); 1 the mix described below; 2 every halo through the pipeline
     { const char *e = getenv("SOAP_ENGINE_PIPELINE"); pipeline = pipeline && e && atoi(e) != 0; }

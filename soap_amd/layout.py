@@ -18,7 +18,11 @@ CALC_FLAG_DM_FLOW = 1
 CALC_FLAG_ROTATION = 2
 CALC_FLAG_INERTIA = 4
 CALC_FLAG_STRICT_COPY = 8
+CALC_FLAG_PROPERTY_RADIUS = 16
 STATS_COLUMNS = 6   # SOAP_STATS_COLUMNS
+# SOAP_RADIUS_*: bound-subhalo properties an aperture radius can be a multiple of (internal key -> id)
+RADIUS_PROPERTIES = {"HalfMassRadiusTot": 0, "HalfMassRadiusDM": 1, "HalfMassRadiusGas": 2, "HalfMassRadiusStar": 3,
+                     "HalfMassRadiusBaryon": 4, "EncloseRadius": 5}
 
 # total / dark matter / gas / stellar inertia tensors, in column order
 INERTIA_KEYS = (

@@ -30,11 +30,8 @@ class ApertureProperties(HaloProperty):
                  recently_heated_gas_filter, stellar_age_calculator, cold_dense_gas_filter,
                  category_filter, halo_filter, inclusive, all_radii_kpc):  # fmt: skip
         super().__init__(cellgrid)
-        if aperture_physical_radius_kpc is None or aperture_property is not None:
-            raise NotImplementedError(
-                "apertures defined by another property (aperture_properties.py:3975-3986) are not built yet"
-            )
-        assert aperture_physical_radius_kpc >= 0.001
+        if (aperture_physical_radius_kpc is None) == (aperture_property is None):
+            raise ValueError("an aperture needs either a physical radius or a defining property")
         self.category_filter = category_filter
         self.halo_filter = halo_filter
         self.property_filters = _property_filters(parameters, self)
@@ -45,10 +42,29 @@ class ApertureProperties(HaloProperty):
         # switch is read and kept, and changes no column of a spherical aperture.
         self.strict_halo_copy = bool(parameters.strict_halo_copy()) if hasattr(parameters, "strict_halo_copy") else False
         self.aperture_physical_radius_kpc = aperture_physical_radius_kpc
-        self.aperture_property = None
+        self.aperture_property = aperture_property
         self.inclusive = inclusive
-        self.physical_radius_mpc = 0.001 * aperture_physical_radius_kpc
-        aperture_name = _aperture_name(aperture_physical_radius_kpc)
+        if aperture_physical_radius_kpc is not None:
+            assert aperture_physical_radius_kpc >= 0.001
+            self.physical_radius_mpc = 0.001 * aperture_physical_radius_kpc
+            aperture_name = _aperture_name(aperture_physical_radius_kpc)
+        else:
+            # radius = multiple x a property of the bound subhalo (aperture_properties.py:3973-3981)
+            group, prop = aperture_property[0].split("/")[0], aperture_property[0].split("/")[-1]
+            assert group == "BoundSubhalo"
+            multiplier = aperture_property[1]
+            aperture_name = prop if multiplier == 1 else f"{int(multiplier)}x{prop}"
+            # "used to guess the initial load region for each particle" (:3979-3981)
+            self.physical_radius_mpc = 0
+            from ..property_table import full_property_list
+
+            by_name = {full_property_list[k].name: k for k in layout.RADIUS_PROPERTIES}
+            if prop not in by_name:
+                raise NotImplementedError(
+                    f"aperture radius from {aperture_property[0]}: the engine knows the half-mass radii and the enclose "
+                    f"radius of the bound subhalo ({sorted(by_name)})")
+            self._radius_property = layout.RADIUS_PROPERTIES[by_name[prop]]
+            self._radius_property_key = by_name[prop]
         if inclusive:
             self.name = f"inclusive_sphere_{aperture_name}"
             self.group_name = f"InclusiveSphere/{aperture_name}"
@@ -63,6 +79,17 @@ class ApertureProperties(HaloProperty):
 
     def calc_desc(self, halo_prop_list, position):
         d = self._base_desc()
+        if self.aperture_property is not None:
+            # :4131-4138: the property has to be in halo_result, i.e. enabled for the bound subhalo
+            sub = halo_prop_list[0]
+            if self._radius_property_key not in sub.enabled_properties():
+                raise RuntimeError(f"{self.aperture_property[0]} must be enabled in the parameter file if you want to "
+                                   "use it to define an aperture")
+            d.radius = float(self.aperture_property[1])
+            d.parent = self._radius_property
+            d.flags |= layout.CALC_FLAG_PROPERTY_RADIUS
+            d.physical_radius_mpc = 0.0
+            return d
         d.radius = self.cellgrid.kpc_to_comoving(self.aperture_physical_radius_kpc)
         # skip/copy rule (aperture_properties.py:4082-4123)
         i_radius = self.all_radii_kpc.index(self.aperture_physical_radius_kpc)

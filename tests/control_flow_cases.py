@@ -46,6 +46,18 @@ def variations(dmo, skip_incl):
         ap[f"inclusive_{r:.0f}_kpc"] = {"radius_in_kpc": r, "inclusive": True, "skip_gt_enclose_radius": skip_incl}
         ap[f"exclusive_{r:.0f}_kpc"] = {"radius_in_kpc": r, "inclusive": False,
                                         "filter": ("dm" if dmo else "baryon") if r == RADII_KPC[-1] else "basic"}  # fmt: skip
+    # apertures whose radius is a multiple of a bound-subhalo property (compute_halo_properties.py:403-440)
+    if dmo:
+        ap["exclusive_3xHalfMassRadiusDarkMatter"] = {"property": "BoundSubhalo/HalfMassRadiusDarkMatter", "radius_multiple": 3,
+                                                      "inclusive": False}
+        ap["inclusive_2xEncloseRadius"] = {"property": "BoundSubhalo/EncloseRadius", "radius_multiple": 2, "inclusive": True}
+    else:
+        ap["exclusive_2xHalfMassRadiusStars"] = {"property": "BoundSubhalo/HalfMassRadiusStars", "radius_multiple": 2,
+                                                 "inclusive": False}
+        ap["inclusive_HalfMassRadiusTotal"] = {"property": "BoundSubhalo/HalfMassRadiusTotal", "inclusive": True}
+        ap["inclusive_4xHalfMassRadiusBaryons"] = {"property": "BoundSubhalo/HalfMassRadiusBaryons", "radius_multiple": 4,
+                                                   "inclusive": True, "filter": "baryon"}
+        ap["exclusive_HalfMassRadiusGas"] = {"property": "BoundSubhalo/HalfMassRadiusGas", "inclusive": False}
     pj = {f"projected_{r:.0f}_kpc": {"radius_in_kpc": r} for r in PROJECTED_RADII_KPC}
     return so, ap, pj
 

@@ -274,6 +274,8 @@ def main():
             inclusive=lambda filt, r, radii: AP.InclusiveSphereProperties(cellgrid, params, r, None, None, None, None, cf, filt, radii),
             exclusive=lambda filt, r, radii: AP.ExclusiveSphereProperties(cellgrid, params, r, None, None, None, None, cf, filt, radii),
             projected=lambda filt, r, radii: PJ.ProjectedApertureProperties(cellgrid, params, r, None, cf, filt, radii),
+            inclusive_property=lambda filt, prop: AP.InclusiveSphereProperties(cellgrid, params, None, prop, None, None, None, cf, filt, []),
+            exclusive_property=lambda filt, prop: AP.ExclusiveSphereProperties(cellgrid, params, None, prop, None, None, None, cf, filt, []),
         )
         so_vars, ap_vars, pj_vars = cases.variations(dmo, skip_incl)
         props = chp.build_halo_prop_list(None, None, so_vars, ap_vars, classes=classes, projected_vars=pj_vars)

@@ -46,6 +46,10 @@ def oracle_prop_list(sc, category_filter, SO_variations=None, aperture_vars=None
             u, r, False, radii, halo_filter=filt, filters=f, dmo=dmo),
         projected=lambda filt, r, radii: ho.ProjectedApertureProperties(
             u, r, radii, halo_filter=filt, filters=f, dmo=dmo),
+        inclusive_property=lambda filt, prop: ho.ApertureProperties(
+            u, None, True, [], halo_filter=filt, filters=f, dmo=dmo, aperture_property=prop),
+        exclusive_property=lambda filt, prop: ho.ApertureProperties(
+            u, None, False, [], halo_filter=filt, filters=f, dmo=dmo, aperture_property=prop),
     )  # fmt: skip
     return u, chp.build_halo_prop_list(None, None, SO_variations, aperture_vars, classes=classes,
                                        projected_vars=projected_vars)

@@ -311,6 +311,10 @@ def _oracle_halo_prop_list(g, vname):
         exclusive=lambda filt, r, radii: ho.ApertureProperties(u, r, False, radii, halo_filter=filt, filters=f, dmo=dmo),
         projected=lambda filt, r, radii: ho.ProjectedApertureProperties(u, r, radii, halo_filter=filt, filters=f, dmo=dmo,
                                                                         strict_halo_copy=strict),
+        inclusive_property=lambda filt, prop: ho.ApertureProperties(u, None, True, [], halo_filter=filt, filters=f, dmo=dmo,
+                                                                    aperture_property=prop),
+        exclusive_property=lambda filt, prop: ho.ApertureProperties(u, None, False, [], halo_filter=filt, filters=f, dmo=dmo,
+                                                                    aperture_property=prop),
     )  # fmt: skip
     so_vars, ap_vars, pj_vars = cases.variations(dmo, skip_incl)
     return u, chp.build_halo_prop_list(None, None, so_vars, ap_vars, classes=classes, projected_vars=pj_vars)
