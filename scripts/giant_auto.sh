@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+for w in c3 c2 giant c5; do
+  SOAP_ENGINE_TRACE=1 timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --steps 2 --warmup 1 --passes-per-step 4 > gpurun_out/r2_auto_${w}.json 2> gpurun_out/r2_auto_${w}.err
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r2_auto_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        k=d['kernel_ms']
+        print(f, 'ms_per_pass %.2f halo %.2f wave %.2f wg256 %.2f wg1024 %.2f build %.2f A %.2f B %.2f'%(d['ms_per_pass'],k['halo'],k['halo_wave'],k['halo_wg256'],k['halo_wg1024'],k['pipe_build'],k['pipe_stage_a'],k['pipe_stage_b']), d['halos_by_path'])
+    except Exception as e:
+        print(f,'ERR',e)
+PY

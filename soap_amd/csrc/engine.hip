@@ -1238,9 +1238,31 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         return 0;
     };
     bool pipeline = !want_inertia && !P.has_nu && !P.literal && !want_property_radius;
-    // SOAP_ENGINE_PIPELINE: unset / 0 the single-kernel path (the fastest on the reference configurations so far, DESIGN.md
-    // section 5.3); 1 the mix described below; 2 every halo through the pipeline
-    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); pipeline = pipeline && e && atoi(e) != 0; }
+    // SOAP_ENGINE_PIPELINE: 0 the single-kernel path for every halo; 1 the mix described below; 2 every halo through the
+    // pipeline; 3 (the default) the GIANTS through the pipeline -- halos whose sphere holds more than nb_giant candidates
+    // are built by several workgroups each (k_g* kernels) instead of keeping one 1024-thread group busy for tens of
+    // milliseconds -- and everything else on the single-kernel path, which is the fastest for the small halos
+    int pmode = 3;
+    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); if (e) pmode = atoi(e); }
+    pipeline = pipeline && pmode != 0;
+    // Who is a giant depends on the run: a halo is worth several workgroups when the time ONE thread group needs for it
+    // (a serial chain: ~6e-8 s per candidate on a 256-thread group, measured on c2 / C3) is long against the time the
+    // GPU needs for ALL halos of the run (~1.2e10 candidates per second on the single-kernel path, C3).  On C3 itself
+    // no halo qualifies (its largest halos run beside 1e5 small ones for the same 22 ms); on c2 and on the giant
+    // workload the few large halos ARE the run.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
+    // The multi-workgroup kernels have to find room beside the persistent groups of the other classes, which costs more
+    // than it saves unless the giants are the long pole by a clear margin: factor 2 below (C3 / C5: never).
+    long long nb_giant;
+    {
+        double W = 0.0, est_max = 0.0;
+        for (long long i = 0; i < h->n_halo; i++) { W += (double)std::max<long long>(est[i], 0); est_max = std::max(est_max, (double)est[i]); }
+        const double t_all = W / (P.hydro ? 0.6e10 : 1.2e10) + 1.0e-3;                 // seconds for the whole run
+        const double t_max = est_max * (est_max <= (double)nb_medium ? 6.0e-8 : 3.3e-8);   // its largest halo on one thread group
+        nb_giant = t_max > 2.0 * t_all ? (long long)std::max(t_all * 0.5 / 6.0e-8, 32768.0) : (1ll << 62);
+        const char *e = getenv("SOAP_ENGINE_NB_GIANT");
+        if (e) nb_giant = atoll(e);
+        if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms t_max %.2f ms nb_giant %lld\n", W, est_max, 1e3 * t_all, 1e3 * t_max, nb_giant); fflush(stderr); }
+    }
     h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
     h->n_pipeline = 0;
     h->n_gbuild = 0;
@@ -1252,10 +1274,30 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
     // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
     std::vector<int> early[3];
-    bool hybrid = false;
-    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); hybrid = pipeline && !(e && atoi(e) == 2); }
-    if (hybrid) {
-        for (int k = 1; k < 3; k++) early[k].swap(todo[k]);
+    const bool hybrid = pipeline && pmode == 1;
+    bool giants = pipeline && pmode == 3;
+    if (giants) {
+        // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
+        // the single-kernel path
+        std::vector<int> big;
+        for (int k = 0; k < 3; k++) {
+            for (int i : todo[k]) (est[i] > nb_giant ? big : early[k]).push_back(i);
+            todo[k].clear();
+        }
+        std::sort(big.begin(), big.end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
+        if (big.empty()) {
+            for (int k = 0; k < 3; k++) todo[k].swap(early[k]);
+            pipeline = giants = false;
+        } else {
+            todo[2].swap(big);
+            // the class-2 resources belong to the pipeline: its few small fry joins the 256-thread class
+            early[1].insert(early[1].end(), early[2].begin(), early[2].end());
+            early[2].clear();
+            std::sort(early[1].begin(), early[1].end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
+        }
+    }
+    if (hybrid) for (int k = 1; k < 3; k++) early[k].swap(todo[k]);
+    if (hybrid || giants) {
         int rc = launch_single(early, h->ev_p[0], false);
         if (rc) return rc;
     }
@@ -1346,7 +1388,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 for (int k = 0; k < 3; k++)
                     for (int i : todo[k]) {
                         const long long nb = std::min<long long>(std::max<long long>(est[i], 0), 0xffffffffLL);
-                        const int kc = nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2);
+                        const int kc = giants ? 2 : (nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2));
                         if (hybrid && kc > 0) single[kc].push_back(i);   // the class streams of the large halos are busy
                         else again[kc].push_back(i);
                     }
@@ -1488,6 +1530,16 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
+    {
+        // a sphere that is known not to fit the largest class' slab: grow the slab before the first attempt
+        // instead of finding out by overflowing (the estimate counts every candidate of the first search sphere)
+        long long need = 0;
+        for (int i : todo[2]) need = std::max(need, est[i]);
+        while (caps[2] < cap_max && caps[2] < need + need / 4) {
+            caps[2] = std::min(caps[2] * 2, cap_max);
+            groups[2] = std::max(1, groups[2] / 2);
+        }
+    }
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));

@@ -675,6 +675,21 @@ def test_full_size_invariants_c3(built_library):
     the oracle; at that size the engine is held to size-independent properties: bound-particle counts add up
     to the catalogue's, every SO obeys M = 4/3 pi R^3 rho_ref, radii and masses are ordered the way their
     thresholds are, nested spheres have nested counts, a second run reproduces the table bit for bit."""
+    _full_size_invariants("c3")
+
+
+def test_full_size_invariants_c2(built_library):
+    """configs[1] of BASELINE.json (C2: 1e7 particles, 1e4 halos, BoundSubhalo + SO_200_crit) at full size."""
+    _full_size_invariants("c2")
+
+
+def test_full_size_invariants_giant_halos(built_library):
+    """2e7 particles with the halo-size cap lifted to 1e6 particles (the C3 calculation list): the largest halos go
+    through the 1024-thread groups with slabs of more than a million entries."""
+    _full_size_invariants("giant")
+
+
+def _full_size_invariants(workload):
     import torch
 
     import bench
@@ -682,9 +697,9 @@ def test_full_size_invariants_c3(built_library):
     import time as _t
     _t0 = _t.time()
     def _lap(msg):
-        print(f"[full-size] {msg}: {_t.time() - _t0:.1f} s", flush=True)
-    wl = bench.WORKLOADS["c3"]
-    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0")
+        print(f"[full-size {workload}] {msg}: {_t.time() - _t0:.1f} s", flush=True)
+    wl = bench.WORKLOADS[workload]
+    sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0", max_halo=wl.get("max_halo"))
     cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
     hn = {k: v.cpu().numpy() for k, v in halos.items()}
     H = len(hn["index"])
