@@ -345,7 +345,7 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
-                        const int *ngblock, const int *first_sel, const int *nsel);
+                        const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
 }
 
 // pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
@@ -577,6 +577,8 @@ struct soap_engine {
     size_t gb_count = 0;
     int *d_gints = nullptr;        // rows / tile tables of the large halos
     size_t gints_count = 0;
+    int *d_gbins = nullptr;        // radial bins of the giants' build
+    size_t gbins_count = 0;
     double ms_gbuild = 0;
     long long n_gbuild = 0;
     hipEvent_t ev_p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -757,6 +759,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->d_hdr) (void)hipFree(h->d_hdr);
     if (h->d_gb) (void)hipFree(h->d_gb);
+    if (h->d_gbins) (void)hipFree(h->d_gbins);
     if (h->d_gints) (void)hipFree(h->d_gints);
     for (int k = 0; k < 6; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
     if (h->d_probe) (void)hipFree(h->d_probe);
@@ -1420,14 +1423,22 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (gbuild) small_lists[0] = todo[0];
             else for (int k = 0; k < 3; k++) small_lists[k] = todo[k];
             if (gbuild && (!todo[1].empty() || !todo[2].empty())) {
-                std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, tile_li, gblock_li, sel_li;
+                std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, tile_li, gblock_li, sel_li, bin_first, nbinv;
+                long long nbins_total = 0;
                 for (int k = 1; k < 3; k++) rows.insert(rows.end(), todo[k].begin(), todo[k].end());
                 const size_t L = rows.size();
                 for (size_t li = 0; li < L; li++) {
                     // the selection holds at most est particles: tiles and bucket groups are sized by that
                     const long long e = std::max<long long>(est[rows[li]], 1);
                     const int nt = (int)((e + GTILE - 1) / GTILE);
-                    const int ng = (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
+                    // beyond ~1e6 entries the sample of the sample sort is too thin for its GNBMAX buckets: uniform bins in
+                    // radius instead (~128 entries per bin), as many bucket groups as the entries need
+                    static const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 786432;
+                    const bool giant_sort = e > giant_sort_limit;
+                    const int ng = giant_sort ? (int)(e / 1024 + 2) : (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
+                    const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / 256), 64) : 0;
+                    bin_first.push_back(giant_sort ? (int)nbins_total : -1); nbinv.push_back(nbin);
+                    if (giant_sort) nbins_total += 2ll * nbin + 1 + ng + 1;
                     first_tile.push_back((int)tile_li.size()); ntile.push_back(nt);
                     first_gblock.push_back((int)gblock_li.size()); ngblock.push_back(ng);
                     const int ns = (int)((e + 16383) / 16384);
@@ -1442,7 +1453,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     h->gb_count = L + L / 4 + 16;
                     HIPCHECK(hipMalloc((void **)&h->d_gb, h->gb_count * sizeof(GBuild)));
                 }
-                const size_t nints = 7 * L + tile_li.size() + gblock_li.size() + sel_li.size();
+                if (nbins_total > 0x7fffffffll) return fail(-102, "giants: too many radial bins for one run");
+                if (h->gbins_count < (size_t)nbins_total) {
+                    if (h->d_gbins) (void)hipFree(h->d_gbins);
+                    h->d_gbins = nullptr;
+                    h->gbins_count = (size_t)nbins_total + (size_t)nbins_total / 4 + 64;
+                    HIPCHECK(hipMalloc((void **)&h->d_gbins, h->gbins_count * sizeof(int)));
+                }
+                const size_t nints = 9 * L + tile_li.size() + gblock_li.size() + sel_li.size();
                 if (h->gints_count < nints) {
                     if (h->d_gints) (void)hipFree(h->d_gints);
                     h->d_gints = nullptr;
@@ -1453,19 +1471,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
                 HIPCHECK(hipStreamWaitEvent(cs, h->ev_p[1], 0));
                 int *d = h->d_gints;
-                const std::vector<int> *parts[10] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li};
-                int *dptr[10];
-                for (int q = 0; q < 10; q++) {
+                const std::vector<int> *parts[12] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li,
+                                                     &bin_first, &nbinv};
+                int *dptr[12];
+                for (int q = 0; q < 12; q++) {
                     dptr[q] = d;
                     HIPCHECK(hipMemcpyAsync(d, parts[q]->data(), parts[q]->size() * sizeof(int), hipMemcpyHostToDevice, cs));
                     d += parts[q]->size();
                 }
-                P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6]; P.sel_li = dptr[9];
+                P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6]; P.sel_li = dptr[9]; P.gbins = h->d_gbins;
                 HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
                 HIPCHECK(hipStreamWaitEvent(h->cls[0].stream, h->ev_p[1], 0));   // (class 0 reads the same parameter block: upload first)
                 HIPCHECK(hipEventRecord(C.pstart[0], cs));
                 soap_launch_gbuild(cs, h->d_params, h->arena, (long long)L, (long long)tile_li.size(), (long long)gblock_li.size(),
-                                   (long long)sel_li.size(), dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8]);
+                                   (long long)sel_li.size(), dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8], dptr[10], dptr[11]);
                 HIPCHECK(hipEventRecord(C.pdone[0], cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
                 HIPCHECK(hipStreamWaitEvent(st, C.done, 0));

@@ -139,6 +139,10 @@ struct GBuild {
     int q_unsorted, i_firstpos, i_lastbound, i_firstdm;
     int nbi[4];
     int unequal;         // the masses of the slab are not all the same value
+    // giants (more entries than GNBMAX buckets of a sample sort can split evenly): buckets are uniform bins in radius,
+    // their fills / starts / the starts of the bucket groups live in RunParams.gbins from bin_first on
+    int nbin, bin_first;
+    double bin_scale;    // bin = min(nbin - 1, int(r * bin_scale))
     double splitter[GNBMAX];
     unsigned bcount[GNBMAX];
     int bstart[GNBMAX + 1];
@@ -174,6 +178,7 @@ struct RunParams {
     HaloHdr *hdr;                 // pipeline path: one record per staged halo (null on the single-kernel path)
     GBuild *gb;                   // pipeline path: scratch of the large halos' tile-parallel build
     const int *tile_li, *gblock_li, *sel_li;   // tile / sort block / selection part -> entry of gb
+    int *gbins;                   // radial bins of the giants' build (GBuild.bin_first)
 };
 
 // ------------------------------------------------------------------------------------------

@@ -68,10 +68,11 @@ namespace {
 // only synchronisation between the phases
 extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles,
                                    long long ngblocks, long long nselparts, const int *rows, const int *first_tile, const int *ntile,
-                                   const int *first_gblock, const int *ngblock, const int *first_sel, const int *nsel) {
+                                   const int *first_gblock, const int *ngblock, const int *first_sel, const int *nsel,
+                                   const int *bin_first, const int *nbin) {
     if (nlarge <= 0) return;
     const unsigned g64 = (unsigned)((nlarge + 63) / 64);
-    hipLaunchKernelGGL(k_ginit, dim3(g64), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel);
+    hipLaunchKernelGGL(k_ginit, dim3(g64), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, bin_first, nbin);
     // fixed grids that walk their tiles / bucket groups (a workgroup per tile would cost more in dispatch than in work)
     const unsigned gt = (unsigned)std::min<long long>(ntiles, 256 * 8),
                    gg = (unsigned)std::min<long long>(ngblocks, 256 * 2);

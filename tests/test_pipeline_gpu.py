@@ -44,13 +44,17 @@ def _run(engine, props, sc, halos_np, pipeline, resident=None):
         os.environ.pop("SOAP_ENGINE_PIPELINE", None)
 
 
-@pytest.mark.parametrize("hydro,seed,read_factor,nb_small", [(False, 41, 8.0, None), (True, 42, 8.0, None), (False, 43, 1.5, None),
-                                                             (False, 44, 8.0, 600), (True, 45, 1.5, 2000)])
-def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatch, hydro, seed, read_factor, nb_small):
+@pytest.mark.parametrize("hydro,seed,read_factor,nb_small,giant_sort",
+                         [(False, 41, 8.0, None, None), (True, 42, 8.0, None, None), (False, 43, 1.5, None, None),
+                          (False, 44, 8.0, 600, None), (True, 45, 1.5, 2000, None), (False, 46, 1.5, 600, 3000), (True, 47, 8.0, 2000, 5000)])
+def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatch, hydro, seed, read_factor, nb_small, giant_sort):
     if nb_small is not None:
         # most halos count as LARGE: their slabs are built by several workgroups each (k_g* kernels) in the pipeline,
         # by one 256-thread group on the single-kernel path
         monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", str(nb_small))
+    if giant_sort is not None:
+        # ... and the larger of those are split into uniform radial bins instead of sample-sort buckets (the giants' sort)
+        monkeypatch.setenv("SOAP_ENGINE_GIANT_SORT", str(giant_sort))
     sc, data, halos = make_chunk(250000, 180, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=read_factor)
     data_np, halos_np = to_numpy(data, halos)
     cf = CategoryFilter(dmo=not hydro)
@@ -69,6 +73,14 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
     assert np.array_equal(ha5["read_radius"], ha2["read_radius"]) and np.array_equal(raw5["status"], raw2["status"])
     if nb_small is not None:
         assert n_gbuild > 0.3 * len(halos_np["index"])
+    # giants mode (the default): halos above a limit through the pipeline, the others on the single-kernel path
+    monkeypatch.setenv("SOAP_ENGINE_NB_GIANT", "4000")
+    ha6, _, raw6, t6, (np6, ns6) = _run(engine, props, sc, halos_np, pipeline=3)
+    monkeypatch.delenv("SOAP_ENGINE_NB_GIANT")
+    assert np6 > 0 and np.array_equal(raw6["stats"][:, :3], raw2["stats"][:, :3])
+    scale6 = np.maximum(np.abs(t2).max(axis=0, keepdims=True), 1e-300)
+    assert np.all(np.abs(t6 - t2) <= 1e-11 * np.abs(t2) + 1e-13 * scale6)   # the giants' sums run in 1024-thread groups here
+    assert np.array_equal(ha6["read_radius"], ha2["read_radius"]) and np.array_equal(raw6["status"], raw2["status"])
     assert np.array_equal(raw1["status"], raw2["status"])
     assert np.array_equal(ha1["done"], ha2["done"])
     assert np.array_equal(ha1["read_radius"], ha2["read_radius"])
