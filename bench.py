@@ -309,8 +309,7 @@ def main():
         read radius (their cells are read again, chunk_tasks.py:189-367)."""
         ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
         cur, resident = region, resident0
-        stats = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
-        status = np.full(H, -99, dtype=np.int32)
+        stats = status = None
         table = state["table"]
         t_h = 0.0
         for it in range(8):
@@ -323,8 +322,14 @@ def main():
             t_h += engine.kernel_ms("halo")
             rows = raw["rows"]
             okm = raw["status"] == 0
-            stats[rows[okm]] = raw["stats"][okm]
-            status[rows] = raw["status"]
+            if stats is None and rows.size == H and okm.all():
+                stats, status = raw["stats"], raw["status"]   # every halo finished in the first call: the engine's arrays as they are
+            else:
+                if stats is None:
+                    stats = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
+                    status = np.full(H, -99, dtype=np.int32)
+                stats[rows[okm]] = raw["stats"][okm]
+                status[rows] = raw["status"]
             if table is None:
                 state["ncols"] = engine.row_columns
                 table = state["table"] = torch.zeros((H, state["ncols"]), dtype=torch.float64, device=dev)

@@ -263,6 +263,8 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
     __shared__ unsigned s_i[BLK], s_p[BLK];
+    __shared__ double2 s_pay[BLK * 5];   // the block's payload records, written out as consecutive 16-byte words
+    static_assert(sizeof(Pay) == 80, "payload record is five 16-byte words");
     for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -324,7 +326,19 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
                 r.fof = fof[io];
             }
             r.pad_ = 0.0;
-            pay[q] = r;
+            const double2 *w = (const double2 *)&r;
+#pragma unroll
+            for (int k = 0; k < 5; k++) s_pay[5 * threadIdx.x + k] = w[k];
+        }
+        __syncthreads();
+        // records of one destination run are consecutive in LDS and in memory: word c of the block goes to word
+        // (c % 5) of record s_p[c / 5]; consecutive threads store consecutive 16 bytes
+        {
+            double2 *out = (double2 *)pay;
+            for (unsigned c = threadIdx.x; c < 5u * s_total; c += BLK) {
+                const unsigned t = c / 5u, k = c - 5u * t;
+                out[5ull * s_p[t] + k] = s_pay[c];
+            }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
