@@ -366,6 +366,7 @@ void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev are
 // back one word per halo
 __global__ void k_init_hdr(HaloHdr *hdr, long long n, const long long *off, const int *cap, const double *rbuild) {
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
+        if (cap[i] == 0) continue;   // not a row of this iteration (its property passes may still be reading the record)
         HaloHdr z;
         memset(&z, 0, sizeof(z));
         z.off = off[i]; z.cap = cap[i]; z.pipe_state = PIPE_PENDING; z.R_build = rbuild[i];
@@ -382,7 +383,7 @@ __global__ void k_collect_state(const RunParams *Pp, HaloHdr *hdr, long long n, 
         state[i] = s;
         if (s == PIPE_NEED_SUPERSET) {
             const double limit = fmax(P.halo.read_radius[i], P.halo.resident ? P.halo.resident[i] : 0.0);
-            rbuild[i] = fmin(limit, (hdr[i].R_build > 0.0 ? 3.0 : 1.25) * hdr[i].R_need);   // a second miss: a halo inside a larger one's envelope, reach far
+            rbuild[i] = fmin(limit, (hdr[i].R_build > 0.0 ? 3.0 : P.rebuild_factor) * hdr[i].R_need);   // a second miss: a halo inside a larger one's envelope, reach far
         }
         hdr[i].pipe_state = (s == PIPE_BUILT) ? PIPE_PENDING : s;   // never looked at again unless it is rebuilt
     }
@@ -591,6 +592,7 @@ struct soap_engine {
     size_t gb_count = 0;
     int *d_gints = nullptr;        // rows / tile tables of the large halos
     size_t gints_count = 0;
+    hipEvent_t ev_b[8][2] = {};    // giants' mode: property passes of every pipeline iteration
     int *d_gbins = nullptr;        // radial bins of the giants' build
     size_t gbins_count = 0;
     double ms_gbuild = 0;
@@ -773,6 +775,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->d_hdr) (void)hipFree(h->d_hdr);
     if (h->d_gb) (void)hipFree(h->d_gb);
+    for (int it = 0; it < 8; it++) for (int q = 0; q < 2; q++) if (h->ev_b[it][q]) (void)hipEventDestroy(h->ev_b[it][q]);
     if (h->d_gbins) (void)hipFree(h->d_gbins);
     if (h->d_gints) (void)hipFree(h->d_gints);
     for (int k = 0; k < 6; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
@@ -1271,11 +1274,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // than it saves unless the giants are the long pole by a clear margin: factor 2 below (C3 / C5: never).
     long long nb_giant;
     {
-        double W = 0.0, est_max = 0.0;
-        for (long long i = 0; i < h->n_halo; i++) { W += (double)std::max<long long>(est[i], 0); est_max = std::max(est_max, (double)est[i]); }
+        double W = 0.0, est_max = 0.0, t_max = 0.0;
+        for (long long i = 0; i < h->n_halo; i++) {
+            const double e = (double)std::max<long long>(est[i], 0);
+            W += e; est_max = std::max(est_max, e);
+            t_max = std::max(t_max, e * (e <= (double)nb_medium ? 6.0e-8 : 3.8e-8));   // the halo on ONE thread group of its class
+        }
         const double t_all = W / (P.hydro ? 0.6e10 : 1.2e10) + 1.0e-3;                 // seconds for the whole run
-        const double t_max = est_max * (est_max <= (double)nb_medium ? 6.0e-8 : 3.3e-8);   // its largest halo on one thread group
-        nb_giant = t_max > 2.0 * t_all ? (long long)std::max(t_all * 0.5 / 6.0e-8, 32768.0) : (1ll << 62);
+        nb_giant = t_max > 1.25 * t_all ? (long long)std::max(t_all * 0.5 / 6.0e-8, 32768.0) : (1ll << 62);
         const char *e = getenv("SOAP_ENGINE_NB_GIANT");
         if (e) nb_giant = atoll(e);
         if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms t_max %.2f ms nb_giant %lld\n", W, est_max, 1e3 * t_all, 1e3 * t_max, nb_giant); fflush(stderr); }
@@ -1296,9 +1302,17 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (giants) {
         // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
         // the single-kernel path
+        // (a run in which the giants are the long pole is a lightly loaded GPU: a halo of ten thousand candidates on ONE
+        // wavefront takes milliseconds there -- 6.7 ms measured on an eighth of C3 -- so the wavefront class keeps only
+        // the halos up to nb_small_light)
+        long long nb_small_light = 8192;
+        { const char *e = getenv("SOAP_ENGINE_NB_SMALL_LIGHT"); if (e) nb_small_light = atoll(e); }
         std::vector<int> big;
         for (int k = 0; k < 3; k++) {
-            for (int i : todo[k]) (est[i] > nb_giant ? big : early[k]).push_back(i);
+            for (int i : todo[k]) {
+                if (est[i] > nb_giant) big.push_back(i);
+                else early[(k == 0 && est[i] > nb_small_light) ? 1 : k].push_back(i);
+            }
             todo[k].clear();
         }
         std::sort(big.begin(), big.end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
@@ -1334,12 +1348,16 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(h->pool.alloc((void **)&d_state, n * 4));
         HIPCHECK(h->pool.alloc((void **)&d_rbuild, n * 8));
         P.hdr = h->d_hdr;
+        P.rebuild_factor = giants ? 2.0 : 1.25;   // giants' mode: every extra iteration is a round of launches for a handful of halos
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
-        auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after) -> int32_t {
+        auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after, bool join, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int alt = -1) -> int32_t {
             const int order[3] = {2, 1, 0};
             for (int oi = 0; oi < 3; oi++) {
                 const int k = order[oi];
-                soap_engine::Class &C = h->cls[k];
+                // alt: the stream, todo list and queue of another class carry this launch of the 1024-thread kernels (giants'
+                // mode: the property passes of successive iterations run side by side)
+                soap_engine::Class &C = (k == 2 && alt >= 0) ? h->cls[alt] : h->cls[k];
+                const bool timed = !(k == 2 && alt >= 0);
                 hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
                 if (lists[k].empty()) continue;
                 const long long nt = (long long)lists[k].size();
@@ -1353,7 +1371,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
                 const int nwg = (int)std::min<long long>(groups[k], nt);
                 const RunParams *dp = h->d_params;
-                HIPCHECK(hipEventRecord(C.pstart[mode == 1 ? 0 : 1], cs));
+                if (timed) HIPCHECK(hipEventRecord(C.pstart[mode == 1 ? 0 : 1], cs));
+                if (e0 && k == 2) HIPCHECK(hipEventRecord(e0, cs));
                 if (mode == 1) {
                     if (k == 0) soap_launch_halo_64b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                     else if (k == 1) soap_launch_halo_256b(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
@@ -1363,10 +1382,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     else if (k == 1) soap_launch_halo_256s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                     else soap_launch_halo_1024s(nwg, cs, dp, h->arena, C.d_queue, (const int *)C.d_todo, nt);
                 }
-                HIPCHECK(hipEventRecord(C.pdone[mode == 1 ? 0 : 1], cs));
+                if (timed) HIPCHECK(hipEventRecord(C.pdone[mode == 1 ? 0 : 1], cs));
+                if (e1 && k == 2) HIPCHECK(hipEventRecord(e1, cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
-                HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
-                if (C.pms[mode == 1 ? 0 : 1] == 0.0) C.pms[mode == 1 ? 0 : 1] = -1.0;   // first iteration: measured after the run
+                if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+                if (timed && C.pms[mode == 1 ? 0 : 1] == 0.0) C.pms[mode == 1 ? 0 : 1] = -1.0;   // first iteration: measured after the run
             }
             return 0;
         };
@@ -1382,6 +1402,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 for (int q = 0; q < 2; q++)
                     if (h->cls[k].pms[q] < 0.0) { float m = 0; (void)hipEventElapsedTime(&m, h->cls[k].pstart[q], h->cls[k].pdone[q]); h->cls[k].pms[q] = m > 0 ? m : 1e-6; }
         };
+        long long arena_used = 0;
+        int props_iters = 0;   // giants' mode: iterations whose property passes were timed with their own events
         std::vector<double> rbuild(n, 0.0);         // 0: the default first superset
         std::vector<int> state(n), single[3];       // rows that end up on the single-kernel path
         std::vector<long long> off(n);
@@ -1417,14 +1439,24 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // arena slices: room for every candidate of the superset (what k_estimate counted), a power of two where
             // the fallback sort may pad, never below 256 entries (stage B parks per-calculation values in slab columns)
             long long total = 0;
+            std::fill(capv.begin(), capv.end(), 0);
             for (int k = 0; k < 3; k++)
                 for (int i : todo[k]) {
                     long long c = std::max<long long>(est[i], 256);
                     if (c > 1024) c = next_pow2(c);
                     off[i] = total; capv[i] = (int)c; total += c;
                 }
-            int rc = alloc_arena(h, total);
-            if (rc) return rc;
+            if (giants && iter > 0 && arena_used + total <= h->arena_cap) {
+                // fresh space behind the slices of the earlier iterations, whose property passes may still be running
+                for (int k = 0; k < 3; k++) for (int i : todo[k]) off[i] += arena_used;
+                arena_used += total;
+            } else {
+                if (giants && iter > 0) { HIPCHECK(hipStreamSynchronize(h->cls[2].stream)); if (h->own_streams) HIPCHECK(hipStreamSynchronize(h->cls[1].stream)); }   // no room: wait, lay out afresh
+                int rc0 = alloc_arena(h, giants ? total + total / 2 : total);
+                if (rc0) return rc0;
+                arena_used = total;
+            }
+            int rc = 0;
             HIPCHECK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
             if (iter == 0) HIPCHECK(hipMemsetAsync(d_rbuild, 0, n * 8, st));
@@ -1482,7 +1514,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     HIPCHECK(hipMalloc((void **)&h->d_gints, h->gints_count * sizeof(int)));
                 }
                 soap_engine::Class &C = h->cls[2];
-                hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
+                // (giants' mode: on the main stream, the class stream carries the property passes of the iteration before)
+                hipStream_t cs = giants ? st : (h->own_streams ? C.stream : h->cls[2].stream);
                 HIPCHECK(hipStreamWaitEvent(cs, h->ev_p[1], 0));
                 int *d = h->d_gints;
                 const std::vector<int> *parts[12] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li,
@@ -1507,7 +1540,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             }
             // (the small halos' groups are persistent and would hold all LDS if they started first: the large halos'
             // kernels, which come and go, are enqueued before them)
-            rc = launch_stage(1, small_lists, h->ev_p[1]);
+            rc = launch_stage(1, small_lists, h->ev_p[1], true);
             if (rc) return rc;
             HIPCHECK(hipEventRecord(h->ev_p[2], st));
             // stage 2: one lane per halo (records that are not freshly built are skipped)
@@ -1537,7 +1570,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     if (split && k > 0) { fin2[k].push_back(i | (1 << 29)); fin2[k].push_back(i | (2 << 29)); }
                     else fin2[k].push_back(i);
                 }
-            rc = launch_stage(2, fin2, h->ev_p[3]);
+            // giants' mode: the property passes run on the 1024-thread class' stream while the main stream goes on with the
+            // next iteration (rebuilds of the few halos whose loop ran past their superset, in fresh arena space)
+            if (giants && !fin2[2].empty()) {
+                for (int q = 0; q < 2; q++) if (!h->ev_b[iter][q]) HIPCHECK(hipEventCreate(&h->ev_b[iter][q]));
+                props_iters |= 1 << iter;
+            }
+            rc = launch_stage(2, fin2, h->ev_p[3], !giants, giants ? h->ev_b[iter][0] : nullptr, giants ? h->ev_b[iter][1] : nullptr,
+                              (giants && h->own_streams && (iter & 1)) ? 1 : -1);
             if (rc) return rc;
             HIPCHECK(hipEventRecord(h->ev_p[4], st));
             for (int k = 0; k < 3; k++) { h->n_pipeline += (long long)fin[k].size(); h->cls[k].nh += (long long)fin[k].size(); todo[k].swap(rest[k]); }
@@ -1552,6 +1592,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                         fin[0].size() + fin[1].size() + fin[2].size(), todo[0].size() + todo[1].size() + todo[2].size(), h->ms_build, h->ms_stage_a, h->ms_stage_b);
                 fflush(stderr);
             }
+        }
+        if (giants) {
+            HIPCHECK(hipStreamWaitEvent(st, h->cls[2].done, 0));
+            HIPCHECK(hipStreamSynchronize(h->cls[2].stream));   // (the scratch below is reused by the next call)
+            if (h->own_streams) HIPCHECK(hipStreamSynchronize(h->cls[1].stream));   // odd iterations' property passes
+            h->ms_stage_b = 0.0;   // the passes ran beside the later iterations: their own events
+            for (int it = 0; it < 8; it++)
+                if (props_iters & (1 << it)) { float m = 0; (void)hipEventElapsedTime(&m, h->ev_b[it][0], h->ev_b[it][1]); h->ms_stage_b += m; }
         }
         for (int k = 0; k < 3; k++) { single[k].insert(single[k].end(), todo[k].begin(), todo[k].end()); todo[k].swap(single[k]); }
         h->pool.release(d_off, n * 8); h->pool.release(d_est2, n * 8); h->pool.release(d_cap, n * 4);

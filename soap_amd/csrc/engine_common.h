@@ -179,6 +179,7 @@ struct RunParams {
     GBuild *gb;                   // pipeline path: scratch of the large halos' tile-parallel build
     const int *tile_li, *gblock_li, *sel_li;   // tile / sort block / selection part -> entry of gb
     int *gbins;                   // radial bins of the giants' build (GBuild.bin_first)
+    double rebuild_factor;        // a halo whose loop ran past its superset is rebuilt out to this times the radius it asked for
 };
 
 // ------------------------------------------------------------------------------------------

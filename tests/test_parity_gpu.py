@@ -905,7 +905,7 @@ class _InertiaOff:
         return {n: (False if "InertiaTensor" in n else "basic") for n in names}
 
 
-def test_inertia_tensors(built_library):
+def test_inertia_tensors(built_library, monkeypatch):
     """Total / dark matter inertia tensors of the bound subhalo and of SOs (inertia_tensors.py:19-132):
     iterative ellipsoids that reach into the particles surrounding the SO, fixed-sphere versions, reduced
     versions; fewer than 20 particles give zeros.  Switched off in the parameter file, their 96 columns per
@@ -945,6 +945,9 @@ def test_inertia_tensors(built_library):
     ncols_on = engine.row_columns
     engine.close()
     props_off = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_InertiaOff())
+    # like with like: a run with the tensors stays on the single-kernel path, so does this one (in the giants' mode the
+    # large halos of so small a chunk would go through the 1024-thread pipeline kernels: same values to 1e-11, other sums)
+    monkeypatch.setenv("SOAP_ENGINE_PIPELINE", "0")
     engine, ha2, results2, out2 = _run_engine(sc, data_np, halos_np, props_off)
     assert engine.row_columns == ncols_on - 96 * len(props_off)
     for j in range(len(results2)):
