@@ -1180,6 +1180,23 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         h->pool.release(d_est, (size_t)h->n_halo * 8);
     }
     TRACE("run: estimate done");
+    // ---- class limits follow the load.  A halo is a serial chain on ONE thread group: ~4e-7 s per candidate on a
+    // wavefront (6.7 ms for 16 k candidates, measured alone), ~6e-8 s on 256 threads, ~3.8e-8 s on 1024 threads, however
+    // empty the GPU is; the whole run needs ~W / 1.2e10 s (W: candidates of all halos; half that rate with gas and
+    // stars).  On the full C3 chunk the chains hide behind 1e5 other halos and the limits are the tuned 16384 / 262144;
+    // on an eighth of it (one rank of 8) or on c2 they would BE the run, so no halo may take longer than tau = 3/4 of
+    // the run's own time on its class.  What is too long even for 1024 threads goes through the multi-workgroup
+    // pipeline (giants' mode below).
+    double run_W = 0.0, run_est_max = 0.0;
+    for (long long i = 0; i < h->n_halo; i++) { const double e = (double)std::max<long long>(est[i], 0); run_W += e; run_est_max = std::max(run_est_max, e); }
+    const double run_t_all = run_W / (P.hydro ? 0.6e10 : 1.2e10) + 1.0e-3;
+    const double run_tau = std::max(0.75 * run_t_all, 2.0e-3);
+    const bool load_classes = h->cfg.slab_capacity <= 0 && !getenv("SOAP_ENGINE_NB_SMALL") && !getenv("SOAP_ENGINE_NB_MEDIUM") &&
+                              !(getenv("SOAP_ENGINE_LOAD_CLASSES") && atoi(getenv("SOAP_ENGINE_LOAD_CLASSES")) == 0);
+    if (load_classes) {
+        nb_small = std::min<long long>(nb_small, std::max<long long>(2048, (long long)(run_tau / 4.0e-7)));
+        nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / 6.0e-8)));
+    }
     const auto t_host1 = std::chrono::steady_clock::now();
     // heaviest first inside every class (the reference orders by bound-particle count for the same
     // reason, chunk_tasks.py:118-120); ties keep the staged order.  One sort of packed (estimate, row) keys.
@@ -1265,26 +1282,19 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     int pmode = 3;
     { const char *e = getenv("SOAP_ENGINE_PIPELINE"); if (e) pmode = atoi(e); }
     pipeline = pipeline && pmode != 0;
-    // Who is a giant depends on the run: a halo is worth several workgroups when the time ONE thread group needs for it
-    // (a serial chain: ~6e-8 s per candidate on a 256-thread group, measured on c2 / C3) is long against the time the
-    // GPU needs for ALL halos of the run (~1.2e10 candidates per second on the single-kernel path, C3).  On C3 itself
-    // no halo qualifies (its largest halos run beside 1e5 small ones for the same 22 ms); on c2 and on the giant
-    // workload the few large halos ARE the run.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
-    // The multi-workgroup kernels have to find room beside the persistent groups of the other classes, which costs more
-    // than it saves unless the giants are the long pole by a clear margin: factor 2 below (C3 / C5: never).
-    long long nb_giant;
+    // Giants: the largest halo would keep a 1024-thread group busy for longer than giant_factor * tau (the
+    // multi-workgroup kernels have to find room beside the persistent groups of the other classes, which costs more
+    // than it saves unless the giants are the long pole by a clear margin: C3 and C5 on one GPU never qualify) and is
+    // large enough for the pipeline's fixed latency (~8 ms of dependent launches) to pay.  Then everything beyond the
+    // 256-thread class goes through the pipeline.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
+    long long nb_giant = 1ll << 62;
     {
-        double W = 0.0, est_max = 0.0, t_max = 0.0;
-        for (long long i = 0; i < h->n_halo; i++) {
-            const double e = (double)std::max<long long>(est[i], 0);
-            W += e; est_max = std::max(est_max, e);
-            t_max = std::max(t_max, e * (e <= (double)nb_medium ? 6.0e-8 : 3.8e-8));   // the halo on ONE thread group of its class
-        }
-        const double t_all = W / (P.hydro ? 0.6e10 : 1.2e10) + 1.0e-3;                 // seconds for the whole run
-        nb_giant = t_max > 1.25 * t_all ? (long long)std::max(t_all * 0.5 / 6.0e-8, 32768.0) : (1ll << 62);
+        double giant_factor = 1.0;
+        { const char *e = getenv("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
+        if (run_est_max * 3.8e-8 > giant_factor * run_tau && run_est_max > 2.1e5) nb_giant = nb_medium;
         const char *e = getenv("SOAP_ENGINE_NB_GIANT");
         if (e) nb_giant = atoll(e);
-        if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms t_max %.2f ms nb_giant %lld\n", W, est_max, 1e3 * t_all, 1e3 * t_max, nb_giant); fflush(stderr); }
+        if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms tau %.2f ms limits %lld / %lld giants above %lld\n", run_W, run_est_max, 1e3 * run_t_all, 1e3 * run_tau, nb_small, nb_medium, nb_giant); fflush(stderr); }
     }
     h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
     h->n_pipeline = 0;
@@ -1302,17 +1312,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (giants) {
         // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
         // the single-kernel path
-        // (a run in which the giants are the long pole is a lightly loaded GPU: a halo of ten thousand candidates on ONE
-        // wavefront takes milliseconds there -- 6.7 ms measured on an eighth of C3 -- so the wavefront class keeps only
-        // the halos up to nb_small_light)
-        long long nb_small_light = 8192;
-        { const char *e = getenv("SOAP_ENGINE_NB_SMALL_LIGHT"); if (e) nb_small_light = atoll(e); }
         std::vector<int> big;
         for (int k = 0; k < 3; k++) {
-            for (int i : todo[k]) {
-                if (est[i] > nb_giant) big.push_back(i);
-                else early[(k == 0 && est[i] > nb_small_light) ? 1 : k].push_back(i);
-            }
+            for (int i : todo[k]) (est[i] > nb_giant ? big : early[k]).push_back(i);
             todo[k].clear();
         }
         std::sort(big.begin(), big.end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });

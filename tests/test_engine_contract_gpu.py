@@ -199,7 +199,7 @@ def test_resident_radius_replaces_the_retry_passes(built_library):
     # to a larger thread group the second time (the class follows a work estimate), which rounds sums differently
     scale = np.maximum(np.abs(table_a).max(axis=0, keepdims=True), 1e-300)
     assert np.all(np.abs(table_a - table_b) <= 1e-11 * np.abs(table_a) + 1e-13 * scale)
-    assert np.mean(table_a == table_b) > 0.97
+    assert np.mean(table_a == table_b) > 0.9   # (the class limits follow the load of a call: a later call over few halos uses other groups)
     assert np.array_equal(ha["read_radius"], hb["read_radius"])
     assert np.array_equal(ha["search_radius"], hb["search_radius"])
     assert np.array_equal(stats_a[:, :2], out[4]["stats"][:, :2])
