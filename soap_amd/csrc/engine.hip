@@ -1350,7 +1350,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(h->pool.alloc((void **)&d_state, n * 4));
         HIPCHECK(h->pool.alloc((void **)&d_rbuild, n * 8));
         P.hdr = h->d_hdr;
-        P.rebuild_factor = giants ? 2.0 : 1.25;   // giants' mode: every extra iteration is a round of launches for a handful of halos
+        P.rebuild_factor = giants ? 1.6 : 1.25;   // (stage A already extrapolates the enclosed density to the target; giants: every extra iteration is a round of launches for a handful of halos)
+        { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) P.rebuild_factor = atof(e); }
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
         auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after, bool join, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int alt = -1) -> int32_t {
             const int order[3] = {2, 1, 0};

@@ -189,16 +189,25 @@ __global__ void __launch_bounds__(SA_BLK) k_stage_a(const RunParams *Pp, SlabDev
     long long n_loop = 0, n_loop_all = 0;
     int pipe = PIPE_DONE;
     double R_need = 0.0;
+    double over_R = 0.0, over_density = 0.0;   // last round whose enclosed density was still above the target
     while (true) {
         n_loop++; n_loop_all++;
         if (!(Rcur <= Rread)) { status = SOAP_HALO_FATAL_RADIUS_ASSERT; break; }
-        if (Rcur > R_have) { pipe = PIPE_NEED_SUPERSET; R_need = Rcur; break; }   // the build stage has to reach further
+        if (Rcur > R_have) {
+            // the build stage has to reach further: at least to this round's radius; when the loop is still waiting for
+            // the enclosed density to fall below the target, to where it will have -- beyond a halo the enclosed density
+            // falls about as R^-2 (R^-3 once nothing more is added) -- so that ONE rebuild is enough
+            pipe = PIPE_NEED_SUPERSET; R_need = Rcur;
+            if (over_R > 0.0 && target > 0.0) R_need = fmax(R_need, over_R * sqrt(over_density / target));
+            break;
+        }
         const int n = (Rcur == R_have) ? n_have : count_le(S.q, n_have, Rcur * Rcur);
         n_final = n;
         double required = 0.0;
         // density = mass_total / (4/3 pi R^3) <= target  (halo_tasks.py:97-103)
         const double mass_total = n > 0 ? S.cum[n - 1] : 0.0;
         const double density = mass_total / (4.0 / 3.0 * M_PI * cube(Rcur));
+        if (use_target && density > target) { over_R = Rcur; over_density = density; } else over_R = 0.0;
         if (!use_target || density <= target) {
             int fatal = 0;
             bool stop = false;
