@@ -1573,6 +1573,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     if (split && k > 0) { fin2[k].push_back(i | (1 << 29)); fin2[k].push_back(i | (2 << 29)); }
                     else fin2[k].push_back(i);
                 }
+            if (giants && getenv("SOAP_ENGINE_GIANT_PROPS_CLASS") && atoi(getenv("SOAP_ENGINE_GIANT_PROPS_CLASS")) == 1) {
+                // experiment: the 256-thread variant of the property kernel (256 VGPRs, no spills in the sweeps)
+                fin2[1].insert(fin2[1].end(), fin2[2].begin(), fin2[2].end());
+                fin2[2].clear();
+            }
             // giants' mode: the property passes run on the 1024-thread class' stream while the main stream goes on with the
             // next iteration (rebuilds of the few halos whose loop ran past their superset, in fresh arena space)
             if (giants && !fin2[2].empty()) {
