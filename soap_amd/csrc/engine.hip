@@ -1166,6 +1166,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         nb_small = c0 / 4; nb_medium = c0 * 2;
     }
     { const char *e = getenv("SOAP_ENGINE_G0"); if (e) groups[0] = atoi(e); }
+    { const char *e = getenv("SOAP_ENGINE_G1"); if (e) groups[1] = atoi(e); }
+    { const char *e = getenv("SOAP_ENGINE_G2"); if (e) groups[2] = atoi(e); }
     if (h->cfg.n_workgroups > 0) { groups[0] = h->cfg.n_workgroups * 4; groups[1] = h->cfg.n_workgroups; groups[2] = std::max(1, h->cfg.n_workgroups / 4); }
     // never below 256 entries: stage B parks 3 values per calculation in two slab columns (finalize_moments)
     for (int k = 0; k < 3; k++) caps[k] = std::max(std::min(caps[k], cap_max), 256ll);
