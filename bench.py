@@ -213,7 +213,9 @@ def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
 
     try:
         v1, h1, n1, t1 = run(1, budget_s * 0.5)
-        ncore = max(1, min(share, 64))
+        # one worker per core of this process' share of the host: a one-GPU box of the pool gets 16 cores of a 256-thread
+        # host (the affinity mask does not say so); BENCH_CPU_CORES overrides
+        ncore = max(1, min(share, int(os.environ.get("BENCH_CPU_CORES", "16"))))
         vN, hN, nN, tN = run(ncore, budget_s) if ncore > 1 else (v1, h1, n1, t1)
     finally:
         import shutil
