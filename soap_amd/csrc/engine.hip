@@ -721,6 +721,10 @@ static int32_t create_resources(soap_engine *h) {
     for (int k = 0; k < 3; k++) {
         if (h->own_streams) {
             int prio = k == 0 ? prio_least : (k == 1 ? prio_least - 1 : prio_greatest);
+            if (const char *e = getenv("SOAP_ENGINE_PRIO")) {   // diagnostic: three digits, rank of class 0 / 1 / 2 (0 = least)
+                const int r = e[k] - '0';
+                prio = r == 0 ? prio_least : (r == 1 ? prio_least - 1 : prio_greatest);
+            }
             HIPCHECK(hipStreamCreateWithPriority(&h->cls[k].stream, hipStreamNonBlocking, prio));
         } else {
             HIPCHECK(hipStreamCreate(&h->cls[k].stream));
