@@ -22,8 +22,10 @@ Multi-GPU (BASELINE.json configs[3]): STRONG scaling, the SAME seed-1234 box on 
 into N Peano-Hilbert chunks (soap_amd/core/domain_decomposition.py), rank g gets chunk g and every particle
 of the top-level cells its halos' read spheres overlap (boundary cells replicated, no particle exchange:
 soap_amd/core/chunk_tasks.py), read once before the timed region (the stand-in of the snapshot read); the
-per-rank result tables are concatenated and put in final-catalogue order by `gather_catalogue` (ONE
-all-gather over RCCL/xGMI plus a device sort) inside the timed region.  Until the driver's SCALE run
+per-rank catalogues -- the columns of the result table that are stored, multiplied by their comoving -> stored-unit
+factor and cast to the stored dtype on the device (`PackedLayout.pack`) -- are concatenated and put in
+final-catalogue order by `gather_catalogue_packed` (one all-gather per dtype over RCCL/xGMI plus a device sort)
+inside the timed region.  Until the driver's SCALE run
 exists there is no hardware scaling curve; `replication` in the line says how many particles the chunks
 hold together relative to the box.
 
@@ -269,7 +271,8 @@ def main():
 
     g.build()
     from soap_amd import layout
-    from soap_amd.catalogue import gather_catalogue
+    from soap_amd.catalogue import gather_catalogue_packed
+    from soap_amd.core.result_set import PackedLayout
     from soap_amd.core import chunk_tasks, halo_tasks
     from soap_amd.synthetic import make_chunk
 
@@ -304,6 +307,7 @@ def main():
 
     engine = halo_tasks.make_engine(sc, device=local_rank)
     state = dict(nleft=0, npass=0, ncols=None, raw=None, catalogue=None, table=None)
+    packed = PackedLayout(props, engine.desc_columns)
     ms_halo, ms_mesh, ms_reorder = [], [], []
 
     def one_pass(record):
@@ -354,7 +358,8 @@ def main():
         state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
                             radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
         # final catalogue: concatenation over the ranks in (cell, catalogue index) order
-        state["catalogue"] = gather_catalogue(table, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
+        narrow, wide = packed.pack(table)
+        state["catalogue"] = gather_catalogue_packed(narrow, wide, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
 
     def sync():
         if world > 1:
@@ -435,6 +440,7 @@ def main():
             "halos_unfinished": int(nleft_all),
             "process_halos_calls_per_pass": raw["iterations"], "catalogue_radius_updates": raw["radius_updates"],
             "replication": nregion_all / n_box,
+            "catalogue_bytes_per_halo": {"stored": packed.bytes_per_halo(), "fp64_table": 8 * packed.table_columns},
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
                           "reorder": float(np.mean(ms_reorder)),
                           "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),

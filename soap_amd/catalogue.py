@@ -98,6 +98,51 @@ def gather_catalogue(table: torch.Tensor, cofp: torch.Tensor, index: torch.Tenso
     return gathered[o, 4:], cofp_all[o], index_all[o]
 
 
+def gather_catalogue_packed(narrow: torch.Tensor, wide: torch.Tensor, cofp: torch.Tensor, index: torch.Tensor,
+                             cell_size, dimension, group=None):  # fmt: skip
+    """
+    `gather_catalogue` for the STORED catalogue (`soap_amd.core.result_set.PackedLayout.pack`): narrow [n_local, Nn]
+    float32 and wide [n_local, Nw] float64 instead of the engine's fp64 table.  Two all-gathers (one per dtype; the halo
+    keys travel with the wide one), the padding rule and the ordering are those of `gather_catalogue`.
+    Returns (narrow_all, wide_all, cofp_all, index_all) in final-catalogue order, identical on all ranks.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_local = narrow.shape[0]
+    dev = narrow.device
+
+    def order_of(c, i):
+        if c.is_cuda:
+            return spatial_sort_order_device(c, i, cell_size, dimension)
+        return torch.as_tensor(spatial_sort_order(c.numpy(), i.numpy(), cell_size, dimension))
+
+    if world == 1:
+        o = order_of(cofp, index)
+        return narrow[o], wide[o], cofp[o], index[o]
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts_h = counts.tolist()
+    nmax = max(counts_h)
+    nw = wide.shape[1]
+    pay_w = torch.zeros((nmax, nw + 4), dtype=torch.float64, device=dev)
+    pay_w[:n_local, 0] = index.to(torch.int64).view(torch.float64)
+    pay_w[:n_local, 1:4] = cofp
+    pay_w[:n_local, 4:] = wide
+    pay_n = torch.zeros((nmax, narrow.shape[1]), dtype=torch.float32, device=dev)
+    pay_n[:n_local] = narrow
+    got_w = torch.empty((world * nmax, nw + 4), dtype=torch.float64, device=dev)
+    got_n = torch.empty((world * nmax, narrow.shape[1]), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(got_w, pay_w, group=group)
+    dist.all_gather_into_tensor(got_n, pay_n, group=group)
+    if min(counts_h) != nmax:
+        keep = torch.cat([torch.arange(int(c), device=dev) + r * nmax for r, c in enumerate(counts_h)])
+        got_w, got_n = got_w[keep], got_n[keep]
+    index_all = got_w[:, 0].contiguous().view(torch.int64)
+    cofp_all = got_w[:, 1:4].contiguous()
+    o = order_of(cofp_all, index_all)
+    return got_n[o], got_w[o, 4:], cofp_all[o], index_all[o]
+
+
 def partition_halos(cofp: np.ndarray, n_chunks: int, boxsize: float, bits: int = 10):
     """
     Assign halos to `n_chunks` spatially compact, equal-count chunks by sorting the centres

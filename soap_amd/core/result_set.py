@@ -94,6 +94,26 @@ class ResultSet:
         self.meta.setdefault(name, {"unit": unit, "description": desc, "output_physical": bool(physical),
                                     "a_scale_exponent": a_exp, "dtype": str(values.dtype)})  # fmt: skip
 
+    def append_packed(self, packed: "PackedLayout", narrow, wide, halo_arrays: Dict[str, np.ndarray]) -> None:
+        """The same columns as `append_table`, from the packed catalogue (`PackedLayout.pack`, possibly gathered from
+        several GPUs): host arrays narrow [n, Nn] float32, wide [n, Nw] float64."""
+        narrow, wide = np.asarray(narrow), np.asarray(wide)
+        n = narrow.shape[0]
+        if n == 0:
+            return
+        for name, kind, c0, nc, dtype, unit, desc, physical, a_exp in packed.fields:
+            if kind == "zero":
+                vals = np.zeros((n, nc), dtype=dtype)
+            elif kind == "narrow":
+                vals = narrow[:, c0 : c0 + nc]
+            else:
+                vals = wide[:, c0 : c0 + nc].astype(dtype)
+            self._put(name, vals[:, 0].copy() if nc == 1 else vals.copy(), unit, desc, physical, a_exp)
+        for src, (name, dtype, desc, phys, aexp) in _INPUT_HALO_COLUMNS.items():
+            unit = "snap_length" if src == "cofp" else "dimensionless"
+            self._put(name, np.asarray(halo_arrays[src]).astype(dtype), unit, desc, phys, aexp)
+        self.n_halo += n
+
     # -- reading ------------------------------------------------------------------------------
     def columns(self) -> Dict[str, np.ndarray]:
         return {k: np.concatenate(v, axis=0) for k, v in self._chunks.items()}
@@ -115,6 +135,79 @@ class ResultSet:
         np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in cols.items()})
         with open(path + ".json", "w") as f:
             json.dump(self.meta, f, indent=1, sort_keys=True)
+
+
+class PackedLayout:
+    """
+    Which columns of the engine's fp64 table end up in the catalogue, and as what: what `ResultSet.append_table` does
+    on the host, turned into index lists so that the cut, the comoving -> stored-unit factor and the cast can run on the
+    device BEFORE the catalogue leaves the GPU (the all-gather then moves the stored catalogue -- float32 for most
+    datasets, about a quarter of the bytes of the fp64 table for a dark-matter-only run -- instead of every column of the
+    table).  `narrow`: datasets stored as float32; `wide`: float64 datasets and the integer ones (carried as float64,
+    exact, cast when the columns are cut out).
+    """
+
+    def __init__(self, halo_prop_list: List, engine_desc_columns):
+        props = list(halo_prop_list)
+        ncols = [int(engine_desc_columns(hp.calc_desc(props, i))) for i, hp in enumerate(props)]
+        coloff = np.concatenate([[0], np.cumsum(ncols)]).astype(np.int64)
+        self.table_columns = int(coloff[-1])
+        narrow_cols, narrow_scale, wide_cols, wide_scale = [], [], [], []
+        self.fields = []   # (dataset name, kind, first column in its matrix, width, dtype, unit, description, physical, a-exponent)
+        for ci, hp in enumerate(props):
+            cols = layout.columns_of(hp.kind)
+            for iproj, (proj, base) in enumerate(_projections(hp)):
+                for key in hp.enabled_properties():
+                    prop = full_property_list[key]
+                    filt = hp.property_filters.get(prop.name, "basic")
+                    if ci > 0 and filt != "basic":
+                        raise NotImplementedError(f"property-level category filter {filt!r} of {hp.group_name}/{prop.name}: use ResultSet.append_table")
+                    name = f"{hp.group_name}{proj}/{prop.name}"
+                    meta = (prop.unit, prop.description, prop.output_physical, prop.a_scale_exponent)
+                    if key in layout.VIRTUAL_ZERO_KEYS:
+                        self.fields.append((name, "zero", 0, prop.shape, prop.dtype) + meta)
+                        continue
+                    if hp.kind == layout.CALC_PROJECTED:
+                        c0, nc = layout.projected_columns(key, iproj)
+                    else:
+                        c0, nc = cols[key]
+                        c0 += base
+                    idx = [int(coloff[ci]) + c0 + k for k in range(nc)]
+                    if np.dtype(prop.dtype) == np.float32:
+                        self.fields.append((name, "narrow", len(narrow_cols), nc, prop.dtype) + meta)
+                        narrow_cols += idx
+                        narrow_scale += [hp.a**prop.a_power if prop.a_power else 1.0] * nc
+                    else:
+                        self.fields.append((name, "wide", len(wide_cols), nc, prop.dtype) + meta)
+                        wide_cols += idx
+                        integer = np.issubdtype(np.dtype(prop.dtype), np.integer)
+                        wide_scale += [1.0 if (integer or not prop.a_power) else hp.a**prop.a_power] * nc
+        self.narrow_cols = np.asarray(narrow_cols, dtype=np.int64)
+        self.narrow_scale = np.asarray(narrow_scale, dtype=np.float64)
+        self.wide_cols = np.asarray(wide_cols, dtype=np.int64)
+        self.wide_scale = np.asarray(wide_scale, dtype=np.float64)
+        self._dev = {}
+
+    def bytes_per_halo(self) -> int:
+        return 4 * len(self.narrow_cols) + 8 * len(self.wide_cols)
+
+    def pack(self, table):
+        """table [n, table_columns] float64 (torch tensor on any device, or ndarray) -> (narrow float32 [n, Nn], wide
+        float64 [n, Nw]): value * a**a_power in float64, then ONE cast -- what `_cast` does on the host."""
+        if isinstance(table, np.ndarray):
+            narrow = np.zeros((table.shape[0], len(self.narrow_cols)), dtype=np.float32)
+            narrow += table[:, self.narrow_cols] * self.narrow_scale[None, :]
+            return narrow, table[:, self.wide_cols] * self.wide_scale[None, :]
+        import torch
+
+        key = str(table.device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.as_tensor(x, device=table.device) for x in
+                                   (self.narrow_cols, self.narrow_scale, self.wide_cols, self.wide_scale))
+        nc, ns, wc, ws = self._dev[key]
+        narrow = (table.index_select(1, nc) * ns[None, :]).to(torch.float32)
+        wide = table.index_select(1, wc) * ws[None, :]
+        return narrow, wide
 
 
 def _projections(hp):

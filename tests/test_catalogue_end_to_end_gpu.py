@@ -100,7 +100,37 @@ def test_written_catalogue_equals_the_oracle_catalogue(built_library, tmp_path, 
         chunk_tasks.run_chunk_task(engine, snapshot, props, sc, chunk_halos, wrap=True, results=rs, log=log)
         assert np.all(chunk_halos["done"] == 1)
         n_iterations += len(log)
+    # the multi-GPU route of the same catalogue: every chunk's rows packed on the device (stored dtypes), concatenated in
+    # final order by gather_catalogue_packed, columns cut on the host -- must be the ResultSet above, bit for bit
+    import torch
+
+    from soap_amd.catalogue import gather_catalogue_packed
+    from soap_amd.core.result_set import PackedLayout
+
+    packed = PackedLayout(props, engine.desc_columns)
+    parts = []
+    for chunk_halos in chunk_tasks.split_halos(halos_np, sc.boxsize, nr_chunks):
+        raw_tables = []
+        chunk_tasks.run_chunk_task(engine, snapshot, props, sc, chunk_halos, wrap=True, raw_tables=raw_tables)
+        for rt in raw_tables:
+            narrow, wide = packed.pack(torch.as_tensor(rt["table"], device="cuda:0"))
+            parts.append((narrow, wide, rt["cofp"], rt["index"], rt["is_central"], rt["nr_bound_part"]))
+    narrow = torch.cat([p[0] for p in parts]); wide = torch.cat([p[1] for p in parts])
+    cofp_all = np.concatenate([p[2] for p in parts]); index_all = np.concatenate([p[3] for p in parts])
+    n_all, w_all, c_all, i_all = gather_catalogue_packed(narrow, wide, torch.as_tensor(cofp_all, device="cuda:0"),
+                                                        torch.as_tensor(index_all, device="cuda:0"), list(snapshot.cell_size), dimension)
+    by_index = {int(ix): k for k, ix in enumerate(index_all)}
+    perm = np.array([by_index[int(ix)] for ix in i_all.cpu().numpy()])
+    rs_packed = ResultSet(props, engine.desc_columns)
+    rs_packed.append_packed(packed, n_all.cpu().numpy(), w_all.cpu().numpy(),
+                            dict(cofp=c_all.cpu().numpy(), index=i_all.cpu().numpy(), is_central=np.concatenate([p[4] for p in parts])[perm],
+                                 nr_bound_part=np.concatenate([p[5] for p in parts])[perm]))
     engine.close()
+    ref_cols = rs.sorted_columns(list(snapshot.cell_size), list(dimension))
+    pk_cols = rs_packed.columns()
+    assert set(ref_cols) == set(pk_cols)
+    for k in ref_cols:
+        assert ref_cols[k].dtype == pk_cols[k].dtype and np.array_equal(ref_cols[k], pk_cols[k], equal_nan=True), k
     assert n_iterations > nr_chunks, "the box should need at least one read-radius retry"
     path = str(tmp_path / "catalogue")
     rs.write(path, cell_size=list(snapshot.cell_size), dimension=list(dimension))

@@ -167,3 +167,41 @@ def test_property_table_rows_are_the_references():
                prop.output_physical, prop.a_scale_exponent)
         want = (r["name"], r["shape"], r["dtype"], r["unit"], r["dmo_property"], r["output_physical"], r["a_scale_exponent"])
         assert got == want, (key, got, want)
+
+
+def test_packed_catalogue_equals_the_columns_cut_on_the_host():
+    """PackedLayout (what leaves the GPU in a multi-GPU run: stored dtypes, comoving -> stored-unit factor applied) against
+    ResultSet.append_table (the host path) on a random table with the real layouts: every dataset bit for bit, same
+    metadata, NumPy and torch packers identical.  soap_engine_desc_columns is a pure function: no GPU needed."""
+    import torch
+
+    from soap_amd import compute_halo_properties as chp
+    from soap_amd import layout
+    from soap_amd.core.category_filter import CategoryFilter
+    from soap_amd.core.result_set import PackedLayout, ResultSet
+
+    for hydro in (False, True):
+        sc = SnapshotScalars()
+        cf = CategoryFilter(dmo=not hydro)
+        props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)),
+                                         projected_vars=chp.projected_variations((30.0,)) if hydro else {})
+        pk = PackedLayout(props, layout.desc_columns)
+        rng = np.random.default_rng(1)
+        n = 37
+        table = rng.normal(size=(n, pk.table_columns)) * 10.0 ** rng.integers(-3, 6, size=(n, pk.table_columns))
+        for name, kind, c0, nc, dtype, *_ in pk.fields:
+            if kind == "wide" and np.issubdtype(np.dtype(dtype), np.integer):
+                table[:, pk.wide_cols[c0 : c0 + nc]] = rng.integers(0, 5000, size=(n, nc))
+        ha = dict(cofp=rng.uniform(0, 100, (n, 3)), index=np.arange(n), is_central=np.ones(n, dtype=np.int64), nr_bound_part=np.arange(n))
+        a = ResultSet(props, layout.desc_columns)
+        a.append_table(table, ha)
+        narrow, wide = pk.pack(table)
+        b = ResultSet(props, layout.desc_columns)
+        b.append_packed(pk, narrow, wide, ha)
+        ca, cb = a.columns(), b.columns()
+        assert set(ca) == set(cb) and a.meta == b.meta
+        for k in ca:
+            assert ca[k].dtype == cb[k].dtype and ca[k].shape == cb[k].shape and np.array_equal(ca[k], cb[k]), k
+        n2, w2 = pk.pack(torch.from_numpy(table))
+        assert np.array_equal(n2.numpy(), narrow) and np.array_equal(w2.numpy(), wide)
+        assert pk.bytes_per_halo() < 0.6 * 8 * pk.table_columns

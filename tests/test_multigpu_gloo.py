@@ -36,6 +36,14 @@ def _worker(rank, world, port, tmpdir):
     assert np.array_equal(i.numpy(), index[order])
     assert np.array_equal(c.numpy(), cofp[order])
     assert np.array_equal(t.numpy(), table[order])
+    # the stored catalogue (float32 datasets + float64 / integer datasets) travels the same way
+    from soap_amd.catalogue import gather_catalogue_packed
+
+    narrow = rng.normal(size=(n, 7)).astype(np.float32)
+    n32, w64, c2, i2 = gather_catalogue_packed(torch.from_numpy(narrow[mine]), torch.from_numpy(table[mine]), torch.from_numpy(cofp[mine]),
+                                               torch.from_numpy(index[mine]), cell_size=L / 4, dimension=(4, 4, 4))  # fmt: skip
+    assert n32.dtype == torch.float32 and np.array_equal(n32.numpy(), narrow[order]) and np.array_equal(w64.numpy(), table[order])
+    assert np.array_equal(i2.numpy(), index[order]) and np.array_equal(c2.numpy(), cofp[order])
     np.save(os.path.join(tmpdir, f"ok{rank}.npy"), i.numpy())
     dist.destroy_process_group()
 
