@@ -1202,10 +1202,18 @@ class RadiusMultipleSOProperties(SOProperties):
         # (NumPy >= 2 promotion), so the radius of this SO is the FLOAT32 product -- pinned at a = 1 by
         # tests/golden/control_flow.npz (search radius handed back by process_single_halo, SO/5xR_500_crit/SORadius);
         # the comoving <-> physical factors around it are applied in float64 here
+        # With a != 1 the float32 value also goes through two unit conversions, each a float32 product (unyt converts
+        # a float32 array with a float32 factor): comoving -> physical Mpc before the multiplication (:3917), physical
+        # Mpc -> comoving when the radius is compared with the particle radii (:425-452) or handed to the scheduler
+        # (halo_tasks.py:168) -- pinned by tests/golden/control_flow_units.npz under that reading of unyt
+        mpc = 1000.0 * self.units.kpc
+        to_mpc32, from_mpc32 = np.float32(self.units.a / mpc), np.float32(mpc / self.units.a)
+        r_mpc32 = np.float32(self.multiple) * (np.float32(r32) * to_mpc32)
+        self._radius_comoving = float(r_mpc32 * from_mpc32)
+        self.physical_radius_mpc = r_mpc32   # stays a float32 number: the scheduler converts it with a float32 factor
         r_mult32 = np.float32(self.multiple) * np.float32(r32)
-        self._radius_comoving = float(r_mult32)
-        self.physical_radius_mpc = self._radius_comoving * self.units.a / (1000.0 * self.units.kpc)
-        # :3920  `multiple * halo_result[key][0]`: the same float32 product, compared with the float64 search radius
+        # :3920  `multiple * halo_result[key][0]`: a float32 product in the comoving unit of the stored radius, compared
+        # with the float64 search radius
         if float(r_mult32) > float(search_radius):
             raise SearchRadiusTooSmallError("SO radius multiple estimate was too small!")
         super().calculate(input_halo, search_radius, data, halo_result)
@@ -1580,7 +1588,11 @@ def process_single_halo(mesh, data, halo_prop_list, units: Units, input_halo, ta
                     stats["final_radius"] = float(current_radius)
                 break
         search_radius = input_halo["search_radius"]
-        required_radius = units.mpc_to_comoving(max_physical_radius_mpc)
+        if isinstance(max_physical_radius_mpc, np.float32):
+            # a radius multiple asked for it (halo_tasks.py:168 converts the float32 quantity with a float32 factor)
+            required_radius = float(max_physical_radius_mpc * np.float32(1000.0 * units.kpc / units.a))
+        else:
+            required_radius = units.mpc_to_comoving(max_physical_radius_mpc)
         if stats is not None:
             stats["n_loop"] = n_loop
         if required_radius > input_halo["read_radius"]:

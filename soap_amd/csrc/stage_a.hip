@@ -55,9 +55,11 @@ SOAP_DEV int so_eval(const SlabView &S, const soap_calc_desc &cd, double Rcur, i
         // parent radius as stored (float32); zero if the parent SO does not exist
         // the FLOAT32 product multiple * R is the radius of this SO (SO_properties.py:3917-3920; see so_eval_lane)
         const float r32 = (float)parent_R;
-        R_phys = (double)((float)cd.radius * r32);
-        *required = ((R_phys * a) / mpc) * mpc / a;
-        if (R_phys > Rcur) return RES_TOO_SMALL;
+        const float to_mpc32 = (float)(a / mpc), from_mpc32 = (float)(mpc / a);
+        const float r_mpc32 = (float)cd.radius * (r32 * to_mpc32);
+        R_phys = (double)(r_mpc32 * from_mpc32);
+        *required = R_phys;
+        if ((double)((float)cd.radius * r32) > Rcur) return RES_TOO_SMALL;
     } else if (cd.kind == SOAP_CALC_SO_PHYSICAL) {
         R_phys = cd.radius;
     }

@@ -9,6 +9,9 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "control_flow.npz")
+# the same cases at a = 0.769 with quantities that carry units (comoving coordinates, physical densities ...): every
+# comoving <-> physical conversion is the reference's own (tests/golden/_shims_units)
+GOLDEN_UNITS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "control_flow_units.npz")
 
 # category filters (core/category_filter.py: limit on the summed particle numbers of the bound subhalo)
 FILTERS = {
@@ -65,8 +68,8 @@ def variations(dmo, skip_incl):
 class Golden:
     """Reader of the packed fixture."""
 
-    def __init__(self):
-        self.z = np.load(GOLDEN)
+    def __init__(self, units=False):
+        self.z = np.load(GOLDEN_UNITS if units else GOLDEN)
 
     def scalars(self):
         return {k.split("|")[1]: float(self.z[k]) for k in self.z.files if k.startswith("scalars|")}

@@ -64,9 +64,23 @@ class PlainSharedArray:
         pass
 
 
-def wrap_shared(arr):
+UNITS_MODE = "--units" in sys.argv   # second fixture: a = 0.769..., quantities carry units (tests/golden/_shims_units)
+
+# units of the snapshot datasets and of the halo table, as swift_cells.py / halo_centres.py hand them over
+LEN_C = "snap_length*a"   # comoving length
+DATA_UNITS = {"Coordinates": LEN_C, "Velocities": "snap_length/snap_time", "Masses": "snap_mass", "DynamicalMasses": "snap_mass",
+              "GroupNr_bound": "dimensionless", "FOFGroupIDs": "dimensionless"}
+
+
+def Q(x, units=None, dtype=None):
+    import unyt
+
+    return unyt.unyt_array(np.array(x, dtype=dtype), units=units)
+
+
+def wrap_shared(arr, units=None):
     s = PlainSharedArray.__new__(PlainSharedArray)
-    s.full = mg.U(arr)
+    s.full = Q(arr, units)
     s.local = s.full
     return s
 
@@ -94,13 +108,19 @@ IN_SCOPE = {
 }  # fmt: skip
 
 
+# (properties left out of the unit-aware vectors: none -- the stand-in follows unyt's rule that a ratio of quantities of the
+# same dimensions is plainly dimensionless, which is what keeps the reference's `assert val.units == dimensionless` true
+# for comoving coordinates)
+UNPINNED_WITH_UNITS = set()
+
+
 class Parameters:
     """ParameterFile stand-in (core/parameter_file.py:85-154, :332-338)."""
 
     record_property_timings = False
 
     def __init__(self, table, strict=False):
-        self.names = {cls: {table[k].name for k in keys} for cls, keys in IN_SCOPE.items()}
+        self.names = {cls: {table[k].name for k in keys if k not in UNPINNED_WITH_UNITS} for cls, keys in IN_SCOPE.items()}
         self.strict = strict
 
     def get_property_filters(self, base_halo_type, names):
@@ -115,7 +135,13 @@ class Parameters:
 
 def main():
     mg._install_stubs()
+    if UNITS_MODE:
+        sys.path.insert(0, os.path.join(HERE, "_shims_units"))
     import unyt
+
+    A_EXP = 0.76923077 if UNITS_MODE else 1.0
+    if UNITS_MODE:
+        unyt.define_golden_system(A_EXP, 1.0e-3, 43.00917552)
 
     from SOAP.core import halo_tasks as ref_tasks
     from SOAP.core import shared_mesh as ref_mesh
@@ -137,7 +163,8 @@ def main():
         def __getattr__(self, name):
             return getattr(unyt, name)
 
-    ref_tasks.unyt = UnytWithQuantityUnits()
+    if not UNITS_MODE:
+        ref_tasks.unyt = UnytWithQuantityUnits()
     ref_mesh.shared_array.SharedArray = PlainSharedArray
     ref_mesh.ps.parallel_sort = parallel_sort_stand_in
     ref_mesh.MPI.MIN = "min"
@@ -158,7 +185,7 @@ def main():
         pos = rng.uniform(lo, hi, (n, 3))
         if res == 13:
             pos[:50] = pos[0]   # many particles on one spot
-        m = ref_mesh.SharedMesh(comm, wrap_shared(pos), res)
+        m = ref_mesh.SharedMesh(comm, wrap_shared(pos, LEN_C), res)
         case = dict(res=np.array(res), pos=pos, pos_min=np.asarray(m.pos_min, dtype=float), pos_max=np.asarray(m.pos_max, dtype=float),
                     cell_size=np.asarray(m.cell_size, dtype=float), cell_count=np.asarray(m.cell_count.full),
                     cell_offset=np.asarray(m.cell_offset.full))
@@ -170,7 +197,7 @@ def main():
                 centre = pos[0].copy() % L
             if q == 1:
                 centre = np.array([99.5, 0.2, 50.0])   # the sphere crosses two faces of the box
-            idx = m.query_radius_periodic(mg.U(centre), radius, wrap_shared(pos), L)
+            idx = m.query_radius_periodic(Q(centre, LEN_C), Q(radius, LEN_C), wrap_shared(pos, LEN_C), Q(L, LEN_C))
             queries.append((centre, radius, np.sort(np.asarray(idx)).astype(np.int64)))
         case["q_centre"] = np.array([q[0] for q in queries])
         case["q_radius"] = np.array([q[1] for q in queries])
@@ -194,9 +221,9 @@ def main():
 
     from oracle import halo_oracle as ho   # only for the LIST of property keys the oracle restates
 
-    sc0 = dataclasses.replace(SnapshotScalars(), a=1.0, boxsize=40.0)
+    sc0 = dataclasses.replace(SnapshotScalars(), a=A_EXP, boxsize=40.0)
     kpc = 1.0e-3
-    G = float(unyt.Unit("newton_G"))
+    G = unyt.Unit("newton_G").factor if UNITS_MODE else float(unyt.Unit("newton_G"))
     scal = dict(boxsize=sc0.boxsize, critical_density=sc0.critical_density, mean_density=sc0.mean_density, G=G, kpc=kpc,
                 softening=0.0114, virBN98=sc0.virBN98, H=sc0.H, Omega_g=sc0.Omega_g, Omega_m=sc0.Omega_m)
     for k, v in scal.items():
@@ -204,24 +231,24 @@ def main():
 
     class CellGrid:
         snap_unit_registry = None
-        a_unit = unyt.Unit(1.0)
-        a = 1.0
-        z = 0.0
-        observer_position = mg.U(np.zeros(3))
+        a_unit = unyt.Unit("a") if UNITS_MODE else unyt.Unit(1.0)
+        a = A_EXP
+        z = 1.0 / A_EXP - 1.0
+        observer_position = Q(np.zeros(3), LEN_C)
         snapshot_datasets = mg.DS
 
         def __init__(self):
-            self.critical_density = mg.U(scal["critical_density"])
-            self.mean_density = mg.U(scal["mean_density"])
-            self.boxsize = mg.U(scal["boxsize"])
+            self.critical_density = Q(scal["critical_density"], "snap_mass/snap_length**3")
+            self.mean_density = Q(scal["mean_density"], "snap_mass/snap_length**3")
+            self.boxsize = Q(scal["boxsize"], LEN_C)
             self.virBN98 = scal["virBN98"]
-            s = mg.U(scal["softening"])
+            s = Q(scal["softening"], "snap_length")
             self.baryon_softening = self.dark_matter_softening = self.nu_softening = s
             self.cosmology = {"Omega_nu_0": 0.0, "H0 [internal units]": 1.0, "H [internal units]": scal["H"],
                               "Omega_g": scal["Omega_g"], "Omega_m": scal["Omega_m"]}
 
         def get_unit(self, name):
-            return unyt.Unit(1.0)
+            return unyt.Unit(name) if UNITS_MODE else unyt.Unit(1.0)
 
     cellgrid = CellGrid()
     table = PropertyTable.full_property_list
@@ -259,7 +286,7 @@ def main():
         bdata, halos = boxes[bname]
         params = Parameters(table, strict=strict)
         if not dmo:
-            params.names = {cls: {table[k].name for k in keys} for cls, keys in hydro_scope.items()}
+            params.names = {cls: {table[k].name for k in keys if k not in UNPINNED_WITH_UNITS} for cls, keys in hydro_scope.items()}
         cf = CategoryFilter(cases.FILTERS, dmo=dmo)
         # get_do_calculation's default dictionary (category_filter.py:69-71) is shared by every call in the process and a
         # DMO filter writes zero gas / star / black hole numbers into it: a production run has ONE filter per process,
@@ -288,7 +315,8 @@ def main():
         udata, mesh = {}, {}
         for pt, d in bdata.items():
             # black holes carry DynamicalMasses in the snapshot (snapshot_datasets / mass_dataset of the reference)
-            udata[f"PartType{pt}"] = {("DynamicalMasses" if (pt == 5 and k == "Masses") else k): wrap_shared(v) for k, v in d.items()}
+            udata[f"PartType{pt}"] = {("DynamicalMasses" if (pt == 5 and k == "Masses") else k): wrap_shared(v, DATA_UNITS[k])
+                                      for k, v in d.items()}
             mesh[f"PartType{pt}"] = ref_mesh.SharedMesh(comm, udata[f"PartType{pt}"]["Coordinates"], cases.MESH_RESOLUTION)
         out[f"{vname}|mesh_resolution"] = np.array(cases.MESH_RESOLUTION)
         # halo_tasks.py:306-317
@@ -311,11 +339,11 @@ def main():
             raised = None
             for attempt in range(10):
                 input_halo = {
-                    "cofp": mg.U(halos["cofp"][i].copy()), "index": mg.U(halos["index"][i]), "is_central": mg.U(halos["is_central"][i]),
-                    "nr_bound_part": mg.U(halos["nr_bound_part"][i]), "search_radius": mg.U(row["search_radius"]),
-                    "read_radius": mg.U(row["read_radius"]), "n_loop": mg.U(row["n_loop"]), "n_process": mg.U(row["n_process"]),
+                    "cofp": Q(halos["cofp"][i].copy(), LEN_C), "index": Q(halos["index"][i]), "is_central": Q(halos["is_central"][i]),
+                    "nr_bound_part": Q(halos["nr_bound_part"][i]), "search_radius": Q(row["search_radius"], LEN_C),
+                    "read_radius": Q(row["read_radius"], LEN_C), "n_loop": Q(row["n_loop"]), "n_process": Q(row["n_process"]),
                 }
-                td = mg.U(target_density) if halos["is_central"][i] == 1 else None
+                td = Q(target_density, "snap_mass/snap_length**3") if halos["is_central"][i] == 1 else None
                 try:
                     result, timings = ref_tasks.process_single_halo(mesh, None, udata, props, cellgrid.critical_density,
                                                                     cellgrid.mean_density, cellgrid.boxsize, input_halo, td)
@@ -350,7 +378,8 @@ def main():
             out[f"{tag}|sizes"] = np.array([len(v) for v in vals])
             out[f"{tag}|values"] = np.concatenate(vals)
             out[f"{tag}|float32"] = np.array([np.asarray(result[k][0]).dtype == np.float32 for k in keys])
-    np.savez_compressed(os.path.join(HERE, "control_flow.npz"), **out)
+    out["scalars|a"] = np.array(A_EXP)
+    np.savez_compressed(os.path.join(HERE, "control_flow_units.npz" if UNITS_MODE else "control_flow.npz"), **out)
     print("control-flow golden vectors written:", len(out), "arrays")
 
 

@@ -31,17 +31,21 @@ class _Parameters:
 def _scalars(g):
     s = g.scalars()
     # the unit-less stand-in of the generator: one physical kpc is 1e-3 of the length unit, G as given, a = 1
-    sc = dataclasses.replace(SnapshotScalars(), a=1.0, boxsize=s["boxsize"], U_L=1.0, U_M=1.0, U_t=1.0, kpc_cm=1.0e-3, G_cgs=s["G"])
+    sc = dataclasses.replace(SnapshotScalars(), a=s.get("a", 1.0), boxsize=s["boxsize"], U_L=1.0, U_M=1.0, U_t=1.0, kpc_cm=1.0e-3, G_cgs=s["G"],
+                             comoving_softening=1.0e30)   # (the generator's softening is the maximal physical one at any a)
     assert sc.kpc == s["kpc"] and sc.G == s["G"] and sc.softening == s["softening"]
     assert sc.critical_density == s["critical_density"] and sc.mean_density == s["mean_density"] and sc.virBN98 == s["virBN98"]
     assert sc.H == s["H"] and sc.Omega_g == s["Omega_g"] and sc.Omega_m == s["Omega_m"]
     return sc
 
 
+@pytest.mark.parametrize("units", [False, True])
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("vname", list(cases.VARIANTS))
-def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname, resident):
-    g = cases.Golden()
+def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname, resident, units):
+    """units=True: the vectors made at a = 0.769 with unit-carrying quantities (tests/golden/_shims_units): the reference's
+    own comoving <-> physical conversions and powers of a in every stored value."""
+    g = cases.Golden(units=units)
     bname, dmo, strict, skip_incl = cases.VARIANTS[vname]
     data, halos = g.box(bname)
     sc = _scalars(g)
@@ -49,7 +53,7 @@ def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname
     so_vars, ap_vars, pj_vars = cases.variations(dmo, skip_incl)
     props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars, parameters=_Parameters(strict, not dmo))
     assert [p.name for p in props] == [str(n) for n in g.z[f"{vname}|calc_names"]]
-    assert halo_tasks.target_density_of(props, sc) == float(g.z[f"{vname}|target_density"])
+    assert halo_tasks.target_density_of(props, sc) == pytest.approx(float(g.z[f"{vname}|target_density"]) * sc.a**3, rel=1e-15)
 
     engine = halo_tasks.make_engine(sc, device=0)
     halo_tasks.stage_chunk(engine, data)
@@ -57,6 +61,7 @@ def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname
     ha = dict({k: v.copy() for k, v in halos.items()}, done=np.zeros(H, dtype=np.int32), n_loop=np.zeros(H, dtype=np.float32),
               n_process=np.zeros(H, dtype=np.float32))
     results = []
+    rtol_r = 1e-15 if units else 0.0   # (the stand-in rounds a conversion factor its own way: x * (1/a) against x / a)
     finished_in_call = {}
     n_calls = 0
     for call in range(10):
@@ -75,12 +80,12 @@ def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname
             # one call = one attempt of the reference: same radii going in, same loops, same verdict, same radii coming out
             assert call < len(att), (vname, i, call)
             s_in, r_in, n_loop, done, s_out = att[call]
-            assert before["search_radius"][i] == s_in and before["read_radius"][i] == r_in, (vname, i, call)
+            assert before["search_radius"][i] == pytest.approx(s_in, rel=rtol_r) and before["read_radius"][i] == pytest.approx(r_in, rel=rtol_r), (vname, i, call)
             assert raw["stats"][j, 0] == n_loop and raw["stats"][j, 4] == n_loop and raw["stats"][j, 5] == 1, (vname, i, call, raw["stats"][j])
             assert (raw["status"][j] == 0) == bool(done), (vname, i, call)
-            assert ha["search_radius"][i] == s_out, (vname, i, call, ha["search_radius"][i], s_out)
+            assert ha["search_radius"][i] == pytest.approx(s_out, rel=rtol_r), (vname, i, call, ha["search_radius"][i], s_out)
             if not done:
-                assert ha["read_radius"][i] == max(1.5 * r_in, s_out)   # halo_tasks.py:393-402
+                assert ha["read_radius"][i] == pytest.approx(max(1.5 * r_in, s_out), rel=rtol_r)   # halo_tasks.py:393-402
         for r in results[n0:]:
             finished_in_call[int(r["InputHalos/HaloCatalogueIndex"][0])] = call
         if resident:
@@ -99,7 +104,7 @@ def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname
         res = by_index[int(halos["index"][i])]
         rec = g.record(vname, i)
         # the radii halo_arrays hold at the end, and the bookkeeping columns of --record-halo-timings
-        assert ha["search_radius"][i] == att[-1, 4] and ha["read_radius"][i] == att[-1, 1], (vname, i)
+        assert ha["search_radius"][i] == pytest.approx(att[-1, 4], rel=rtol_r) and ha["read_radius"][i] == pytest.approx(att[-1, 1], rel=rtol_r), (vname, i)
         assert float(res["InputHalos/n_loop"][0]) == float(rec["InputHalos/n_loop"][0][0]) == att[:, 2].sum()
         assert float(res["InputHalos/n_process"][0]) == float(rec["InputHalos/n_process"][0][0]) == len(att)
         for full, (want, is_f32) in rec.items():
