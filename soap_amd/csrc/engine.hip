@@ -1162,7 +1162,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (h->t[0].n > 0 || h->t[2].n > 0) nb_medium = 131072;
     { const char *e = getenv("SOAP_ENGINE_NB_SMALL"); if (e) nb_small = atoll(e); }
     { const char *e = getenv("SOAP_ENGINE_NB_MEDIUM"); if (e) nb_medium = atoll(e); }
-    long long caps[3] = {1ll << 15, 1ll << 18, 1ll << 20};
+    // (twice the class limit: the radius loop may take a sphere a round or two further than the estimate saw, and a halo
+    // that outgrows its slab is done again in the next class, in a pass of its own -- 10 ms on C3 for three seeds in four
+    // when the 256-thread class had no headroom)
+    long long caps[3] = {1ll << 15, 1ll << 19, 1ll << 20};
     int groups[3] = {2048, 512, 128};
     if (h->cfg.slab_capacity > 0) {
         long long c0 = next_pow2(h->cfg.slab_capacity);
@@ -1630,6 +1633,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // instead of finding out by overflowing (the estimate counts every candidate of the first search sphere)
         long long need = 0;
         for (int i : todo[2]) need = std::max(need, est[i]);
+        // (the radius loop may take the sphere a few x1.2 rounds further, x1.7 in content each: room for three of them --
+        // a halo that overflows is done again in a pass of its own, which doubles the time of the largest halo)
+        long long n_top = 0;
+        for (int i : todo[2]) n_top++;
+        while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, 64))) {
+            caps[2] = std::min(caps[2] * 2, cap_max);
+            groups[2] = std::max(1, groups[2] / 2);
+        }
         while (caps[2] < cap_max && caps[2] < need + need / 4) {
             caps[2] = std::min(caps[2] * 2, cap_max);
             groups[2] = std::max(1, groups[2] / 2);
