@@ -450,6 +450,7 @@ def main():
                           "pipe_build_by_class": [engine.kernel_ms("pipe_build_" + c) for c in ("wave", "wg256", "wg1024")],
                           "pipe_props_by_class": [engine.kernel_ms("pipe_props_" + c) for c in ("wave", "wg256", "wg1024")]},
             "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single"))},
+            "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
             "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
                                 int(engine.kernel_ms("n_wg1024"))],
             "roofline": {

@@ -599,6 +599,7 @@ struct soap_engine {
     long long n_gbuild = 0;
     hipEvent_t ev_p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double ms_build = 0, ms_stage_a = 0, ms_stage_b = 0;
+    int n_passes = 0;
     long long n_pipeline = 0, n_single = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
@@ -1165,7 +1166,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // (twice the class limit: the radius loop may take a sphere a round or two further than the estimate saw, and a halo
     // that outgrows its slab is done again in the next class, in a pass of its own -- 10 ms on C3 for three seeds in four
     // when the 256-thread class had no headroom)
-    long long caps[3] = {1ll << 15, 1ll << 19, 1ll << 20};
+    long long caps[3] = {1ll << 16, 1ll << 19, 1ll << 20};
     int groups[3] = {2048, 512, 128};
     if (h->cfg.slab_capacity > 0) {
         long long c0 = next_pow2(h->cfg.slab_capacity);
@@ -1298,7 +1299,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // 256-thread class goes through the pipeline.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
     long long nb_giant = 1ll << 62;
     {
-        double giant_factor = 1.0;
+        // (the busier the GPU, the clearer the margin has to be: beside 1e5 halos the multi-workgroup kernels wait for the
+        // persistent groups to drain -- seed 5 of the C3 box, largest halo 5.7e5 candidates: 32.7 ms with it through the
+        // pipeline, 27.8 ms without)
+        double giant_factor = 1.0 + 0.5 * std::min(1.0, std::max(0.0, (run_t_all - 10.0e-3) / 10.0e-3));
         { const char *e = getenv("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
         if (run_est_max * 3.8e-8 > giant_factor * run_tau && run_est_max > 2.1e5) nb_giant = nb_medium;
         const char *e = getenv("SOAP_ENGINE_NB_GIANT");
@@ -1628,6 +1632,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
+    h->n_passes = 0;
     {
         // a sphere that is known not to fit the largest class' slab: grow the slab before the first attempt
         // instead of finding out by overflowing (the estimate counts every candidate of the first search sphere)
@@ -1665,6 +1670,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             }
         }
         if (!any) break;
+        h->n_passes++;
         HIPCHECK(hipEventRecord(h->ev1, st));
         HIPCHECK(hipMemcpyAsync(status.data(), h->d_status, (size_t)h->n_halo * 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -1685,6 +1691,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     if (k < 2) next[k + 1].push_back(i);
                     else { next[2].push_back(i); grow_top = true; }
                 }
+        if (trace && (next[1].size() || next[2].size())) {
+            long long emax = 0;
+            for (int k = 1; k < 3; k++) for (int i : next[k]) emax = std::max(emax, est[i]);
+            fprintf(stderr, "[soap_engine] pass %d: %zu halos outgrew the wavefront / 256-thread slabs, %zu the 1024-thread slab (largest estimate %lld; slabs %lld / %lld / %lld entries)\n",
+                    pass, next[1].size() + (grow_top ? 0 : next[2].size()), grow_top ? next[2].size() : (size_t)0, emax, caps[0], caps[1], caps[2]);
+            fflush(stderr);
+        }
         if (grow_top) {
             if (caps[2] >= cap_max) break;   // cannot grow further: the status stays fatal
             caps[2] = std::min(caps[2] * 8, cap_max);
@@ -1812,6 +1825,7 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_pipeline")) return (double)h->n_pipeline;
     if (!strcmp(name, "n_gbuild")) return (double)h->n_gbuild;
     if (!strcmp(name, "n_single")) return (double)h->n_single;
+    if (!strcmp(name, "n_passes")) return (double)h->n_passes;   // launches of the single-kernel path (more than one: slab overflows)
     if (!strcmp(name, "mesh")) return h->ms_mesh;
     if (!strcmp(name, "reorder")) return h->ms_reorder;
     return -1.0;
