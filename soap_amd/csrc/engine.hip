@@ -1580,7 +1580,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 }
             // large halos of a run without gas / stars: two groups each, one per family of calculations (stage_b)
             std::vector<int> fin2[3];
-            const bool split = !P.hydro && (getenv("SOAP_ENGINE_SPLIT_PROPS") == nullptr || atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) != 0);
+            // (projected apertures are a pass of the undivided halo: stage_b runs them with part == 0 only)
+            bool any_projected = false;
+            for (int c = 0; c < n_calcs; c++) any_projected = any_projected || calcs[c].kind == SOAP_CALC_PROJECTED;
+            const bool split = !P.hydro && !any_projected && (getenv("SOAP_ENGINE_SPLIT_PROPS") == nullptr || atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) != 0);
             for (int k = 0; k < 3; k++)
                 for (int i : fin[k]) {
                     if (split && k > 0) { fin2[k].push_back(i | (1 << 29)); fin2[k].push_back(i | (2 << 29)); }

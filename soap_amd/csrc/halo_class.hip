@@ -13,6 +13,7 @@
 #define GCH 1024
 #define SORT_NBMAX 64
 #define GLB 4
+#define SCAN_E 4           // consecutive particles per lane in the radial scan (fused_scan)
 #define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #elif GCLASS == 256
@@ -26,6 +27,7 @@
 #endif
 #define SORT_NBMAX 256
 #define GLB 2
+#define SCAN_E 4
 #define GATTR __launch_bounds__(GRP, GLB)
 #define GSYNC() __syncthreads()
 #elif GCLASS == 1024
@@ -36,6 +38,7 @@
 #define GCH 8192
 #define SORT_NBMAX 1024
 #define GLB 4
+#define SCAN_E 4
 #define GATTR __launch_bounds__(GRP, GLB)
 #define GSYNC() __syncthreads()
 #else
