@@ -453,6 +453,7 @@ def main():
             "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
             "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
                                 int(engine.kernel_ms("n_wg1024"))],
+            **({"phase_cycles": engine.phase_cycles()} if os.environ.get("SOAP_ENGINE_PROFILE") == "1" else {}),   # diagnostics
             "roofline": {
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -360,6 +360,7 @@ void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev ar
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
                         const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
+void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart);
 }
 
 // pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
@@ -594,6 +595,8 @@ struct soap_engine {
     size_t gints_count = 0;
     hipEvent_t ev_b[8][2] = {};    // giants' mode: property passes of every pipeline iteration
     int *d_gbins = nullptr;        // radial bins of the giants' build
+    double *d_bpart[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tile sums for the property stage, per pipeline iteration
+    size_t bpart_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t gbins_count = 0;
     double ms_gbuild = 0;
     long long n_gbuild = 0;
@@ -782,6 +785,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_gb) (void)hipFree(h->d_gb);
     for (int it = 0; it < 8; it++) for (int q = 0; q < 2; q++) if (h->ev_b[it][q]) (void)hipEventDestroy(h->ev_b[it][q]);
     if (h->d_gbins) (void)hipFree(h->d_gbins);
+    for (int q = 0; q < 8; q++) if (h->d_bpart[q]) (void)hipFree(h->d_bpart[q]);
     if (h->d_gints) (void)hipFree(h->d_gints);
     for (int k = 0; k < 6; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
     if (h->d_probe) (void)hipFree(h->d_probe);
@@ -1365,6 +1369,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         P.hdr = h->d_hdr;
         P.rebuild_factor = giants ? 1.6 : 1.25;   // (stage A already extrapolates the enclosed density to the target; giants: every extra iteration is a round of launches for a handful of halos)
         { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) P.rebuild_factor = atof(e); }
+        P.g_coarse = getenv("SOAP_ENGINE_G_COARSE") != nullptr && atoi(getenv("SOAP_ENGINE_G_COARSE")) != 0;
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
         auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after, bool join, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int alt = -1) -> int32_t {
             const int order[3] = {2, 1, 0};
@@ -1481,6 +1486,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // several workgroups per halo (k_g* kernels), on the stream of the 1024-thread class
             HIPCHECK(hipEventRecord(h->ev_p[1], st));
             std::vector<int> small_lists[3], none;
+            long long iter_tiles = 0;   // tiles of the large halos built in this iteration
             bool gbuild = getenv("SOAP_ENGINE_GBUILD") == nullptr || atoi(getenv("SOAP_ENGINE_GBUILD")) != 0;
             if (gbuild) small_lists[0] = todo[0];
             else for (int k = 0; k < 3; k++) small_lists[k] = todo[k];
@@ -1553,6 +1559,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
                 if (C.pms[0] == 0.0) C.pms[0] = -1.0;
                 h->n_gbuild += (long long)L;
+                iter_tiles = (long long)tile_li.size();
             }
             // (the small halos' groups are persistent and would hold all LDS if they started first: the large halos'
             // kernels, which come and go, are enqueued before them)
@@ -1561,6 +1568,19 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->ev_p[2], st));
             // stage 2: one lane per halo (records that are not freshly built are skipped)
             soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
+            // large halos whose loop has finished: moment sums of the whole tiles of their search spheres, by all CUs, so that
+            // the one or two groups of the property stage only add them up (reduce_span)
+            const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
+            if (use_bpartials && iter_tiles > 0) {
+                const size_t need = (size_t)iter_tiles * 2 * NACC;
+                if (h->bpart_count[iter] < need) {
+                    if (h->d_bpart[iter]) (void)hipFree(h->d_bpart[iter]);
+                    h->d_bpart[iter] = nullptr;
+                    h->bpart_count[iter] = need + need / 4;
+                    HIPCHECK(hipMalloc((void **)&h->d_bpart[iter], h->bpart_count[iter] * sizeof(double)));
+                }
+                soap_launch_bpartials(st, h->d_params, h->arena, iter_tiles, h->d_bpart[iter]);
+            }
             hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_hdr, (long long)n, d_state, d_rbuild);
             HIPCHECK(hipEventRecord(h->ev_p[3], st));
             HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
@@ -1569,6 +1589,21 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             {
                 hipError_t le = hipGetLastError();
                 if (le != hipSuccess) return fail(-101, std::string("pipeline: ") + hipGetErrorString(le));
+            }
+            if (trace) {
+                // why a halo leaves the pipeline: the scratch record of its tile-parallel build
+                for (int k = 0; k < 3; k++)
+                    for (int i : todo[k])
+                        if (state[i] == PIPE_FALLBACK) {
+                            fprintf(stderr, "[soap_engine] pipeline iteration %d: row %d (estimate %lld) falls back to the single-kernel path", iter, i, est[i]);
+                            if (h->d_gb && iter_tiles > 0) {
+                                std::vector<GBuild> gb((size_t)std::min<size_t>(h->gb_count, (size_t)nrows));
+                                (void)hipMemcpy(gb.data(), h->d_gb, gb.size() * sizeof(GBuild), hipMemcpyDeviceToHost);
+                                for (const GBuild &g : gb)
+                                    if (g.row == i) fprintf(stderr, ": selected %u overflow %d unsorted %d bound %d+%d+%d+%d", g.n, g.overflow, g.q_unsorted, g.nbi[0], g.nbi[1], g.nbi[2], g.nbi[3]);
+                            }
+                            fprintf(stderr, "\n");
+                        }
             }
             // stage 3 for the halos whose loop finished
             std::vector<int> fin[3], rest[3];

@@ -122,6 +122,10 @@ struct HaloHdr {
     double R_final, R_search, R_read, R_need;
     int cs_state[MAXCALC], cs_n[MAXCALC];
     double cs_R[MAXCALC], cs_M[MAXCALC];
+    // ---- written by k_bpartials (large halos): moment sums of whole tiles of the final search sphere, for both families
+    // of calculations: bpart[(2 * tile + family) * NACC + k]; null if there are none
+    double *bpart;
+    int bpart_tiles;        // complete tiles of GTILE entries inside the final search sphere
 };
 
 // Scratch of the tile-parallel build of one LARGE halo (several workgroups per halo, kernels k_g* of
@@ -180,6 +184,7 @@ struct RunParams {
     const int *tile_li, *gblock_li, *sel_li;   // tile / sort block / selection part -> entry of gb
     int *gbins;                   // radial bins of the giants' build (GBuild.bin_first)
     double rebuild_factor;        // a halo whose loop ran past its superset is rebuilt out to this times the radius it asked for
+    int g_coarse;                 // test hook (SOAP_ENGINE_G_COARSE=1): four buckets per large halo, so that every bucket outgrows its LDS block
 };
 
 // ------------------------------------------------------------------------------------------

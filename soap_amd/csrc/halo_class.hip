@@ -90,6 +90,11 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
     hipLaunchKernelGGL(k_gpost, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
+// tile sums for the property stage of the large halos whose radius loop has finished (k_bpartials)
+extern "C" void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_bpartials, dim3((unsigned)std::min<long long>(ntiles, 256 * 8)), dim3(GRP), 0, stream, params, arena, ntiles, bpart);
+}
 #else
 extern "C" void SOAP_CAT3(soap_launch_halo_, GCLASS, SOAP_VARIANT)(int groups, hipStream_t stream, const RunParams *params, SlabDev slab,
                                                                  unsigned *queue, const int *todo, long long n_todo) {

@@ -19,6 +19,17 @@ from tests.test_parity_gpu import compare_halo
 pytestmark = pytest.mark.gpu
 
 
+def engine_columns(engine, props, col):
+    """name of the calculation a table column belongs to, and the column's offset inside its block (diagnostics)"""
+    off = 0
+    for i, p in enumerate(props):
+        w = engine.desc_columns(p.calc_desc(props, i))
+        if col < off + w:
+            return (p.name, col - off)
+        off += w
+    return ("?", col)
+
+
 class _NoInertia:
     """parameter-file stand-in: everything on except the inertia tensors (their iterative passes keep a run on the
     single-kernel path)"""
@@ -55,6 +66,9 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
     if giant_sort is not None:
         # ... and the larger of those are split into uniform radial bins instead of sample-sort buckets (the giants' sort)
         monkeypatch.setenv("SOAP_ENGINE_GIANT_SORT", str(giant_sort))
+    # the bit-for-bit comparisons run without the tile sums of the property stage (k_bpartials: another order of the same
+    # additions for the large halos); they are switched on for a run of their own below
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
     sc, data, halos = make_chunk(250000, 180, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=read_factor)
     data_np, halos_np = to_numpy(data, halos)
     cf = CategoryFilter(dmo=not hydro)
@@ -82,6 +96,13 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
     scale6 = np.maximum(np.abs(t2).max(axis=0, keepdims=True), 1e-300)
     assert np.all(np.abs(t6 - t2) <= 1e-11 * np.abs(t2) + 1e-13 * scale6)   # the giants' sums run in 1024-thread groups here
     assert np.array_equal(ha6["read_radius"], ha2["read_radius"]) and np.array_equal(raw6["status"], raw2["status"])
+    # the property stage of the large halos fed with tile sums computed by all CUs: same selections, sums to rounding
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "1")
+    ha7, _, raw7, t7, (np7, ns7) = _run(engine, props, sc, halos_np, pipeline=2)
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
+    assert np7 == np2 and np.array_equal(raw7["stats"][:, :3], raw2["stats"][:, :3]) and np.array_equal(raw7["status"], raw2["status"])
+    assert np.array_equal(ha7["read_radius"], ha2["read_radius"])
+    assert np.all(np.abs(t7 - t2) <= 1e-11 * np.abs(t2) + 1e-13 * scale6)
     assert np.array_equal(raw1["status"], raw2["status"])
     assert np.array_equal(ha1["done"], ha2["done"])
     assert np.array_equal(ha1["read_radius"], ha2["read_radius"])
@@ -118,3 +139,71 @@ def test_pipeline_equals_single_kernel_path_and_oracle(built_library, monkeypatc
     st = raw2["stats"][raw2["status"] == 0]
     assert np.array_equal(st[:, 0], [s["n_loop"] for s in stats])
     assert np.array_equal(st[:, 1], [s["n_sel"] for s in stats])
+
+
+@pytest.mark.parametrize("hydro,seed", [(False, 51), (True, 52)])
+def test_tile_sums_feed_the_property_stage_of_large_halos(built_library, monkeypatch, hydro, seed):
+    """Halos of tens of thousands of particles through the pipeline: the moment sums of whole 4096-entry tiles of their
+    search spheres come from k_bpartials (all CUs) instead of the one or two groups of the property stage.  Same
+    selections as without them, values to rounding, and the oracle's values."""
+    sc, data, halos = make_chunk(500000, 14, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=8.0)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=not hydro)
+    ap_vars = chp.aperture_variations((30.0, 50.0, 100.0))
+    pj_vars = chp.projected_variations((30.0, 100.0)) if hydro else {}
+    props = chp.build_halo_prop_list(sc, cf, None, ap_vars, projected_vars=pj_vars, parameters=_NoInertia())
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", "2000")
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
+    ha0, res0, raw0, t0, (np0, ns0) = _run(engine, props, sc, halos_np, pipeline=2)
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "1")
+    ha1, res1, raw1, t1, (np1, ns1) = _run(engine, props, sc, halos_np, pipeline=2)
+    colname = lambda c: engine_columns(engine, props, c)  # noqa: E731
+    assert np1 == np0 > 0 and raw1["stats"][:, 1].max() >= 5 * 4096, raw1["stats"][:, 1].max()
+    assert np.array_equal(raw1["stats"][:, :3], raw0["stats"][:, :3]) and np.array_equal(raw1["status"], raw0["status"])
+    assert not np.array_equal(t1, t0)   # the sums did take the other route
+    scale = np.maximum(np.abs(t0).max(axis=0, keepdims=True), 1e-300)
+    excess = np.abs(t1 - t0) / (1e-11 * np.abs(t0) + 1e-11 * scale)   # (off-diagonal dispersion terms are differences of large sums)
+    worst = np.unravel_index(np.argmax(excess), excess.shape)
+    assert excess.max() <= 1.0, (worst, t0[worst], t1[worst], scale[0, worst[1]], colname(worst[1]))
+    engine.close()
+    from oracle import halo_oracle as ho
+
+    saved = ho.ENABLE_INERTIA
+    ho.ENABLE_INERTIA = False
+    try:
+        ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, None, ap_vars, projected_vars=pj_vars)
+    finally:
+        ho.ENABLE_INERTIA = saved
+    assert np.array_equal(ha1["done"], ha_ref["done"])
+    done_rows = np.flatnonzero(ha1["done"] == 1)
+    assert len(res1) == len(done_rows) == len(ref)
+    if not hydro:
+        for j, row in enumerate(done_rows):
+            compare_halo({k: v for k, v in ref[row].items() if "InertiaTensor" not in k}, res1[j], sc)
+    st = raw1["stats"][raw1["status"] == 0]
+    assert np.array_equal(st[:, 1], [s["n_sel"] for s in stats])
+
+
+def test_oversized_sort_buckets_are_ranked(built_library, monkeypatch):
+    """The tile-parallel build splits a large halo into buckets by splitters from a strided sample of the selection;
+    a bucket that outgrows its LDS block is sorted by ranks instead of sending the halo to the single-group build.
+    Forced here (four buckets per halo): same table as the single-kernel path, bit for bit, nobody falls back."""
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
+    monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", "600")
+    sc, data, halos = make_chunk(250000, 60, seed=53, satellite_fraction=0.1, read_radius_factor=8.0)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)), parameters=_NoInertia())
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha1, _, raw1, t1, (np1, ns1) = _run(engine, props, sc, halos_np, pipeline=False)
+    monkeypatch.setenv("SOAP_ENGINE_G_COARSE", "1")
+    ha2, _, raw2, t2, (np2, ns2) = _run(engine, props, sc, halos_np, pipeline=2)
+    n_gbuild = engine.kernel_ms("n_gbuild")
+    engine.close()
+    assert raw1["stats"][:, 1].max() > 4 * 2048 * 2   # buckets of more than two LDS blocks
+    assert np1 == 0 and ns2 == 0 and np2 == len(halos_np["index"]) and n_gbuild > 20, (np1, np2, ns2, n_gbuild)
+    assert np.array_equal(raw1["status"], raw2["status"]) and np.array_equal(raw1["stats"][:, :3], raw2["stats"][:, :3])
+    assert np.array_equal(t1, t2)
