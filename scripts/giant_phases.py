@@ -1,6 +1,6 @@
 """Phase split (shader clocks of thread 0, SOAP_ENGINE_PROFILE=1) of the giant workload's halo kernels."""
 import os, sys
-os.environ["SOAP_ENGINE_PROFILE"] = "1"
+os.environ.setdefault("SOAP_ENGINE_PROFILE", "1")   # n > 1: only the property stage of pipeline halos with n particles and more
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1572,7 +1572,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // the one or two groups of the property stage only add them up (reduce_span)
             const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
             if (use_bpartials && iter_tiles > 0) {
-                const size_t need = (size_t)iter_tiles * 2 * NACC;
+                const size_t need = (size_t)iter_tiles * 2 * (NACC + BSCAN_W);   // tile sums + the tiles' scan records (k_bscan)
                 if (h->bpart_count[iter] < need) {
                     if (h->d_bpart[iter]) (void)hipFree(h->d_bpart[iter]);
                     h->d_bpart[iter] = nullptr;

@@ -126,7 +126,12 @@ struct HaloHdr {
     // of calculations: bpart[(2 * tile + family) * NACC + k]; null if there are none
     double *bpart;
     int bpart_tiles;        // complete tiles of GTILE entries inside the final search sphere
+    // ---- written by k_bscan: per complete tile and family BSCAN_W doubles -- cumulative (mass, dark matter mass, count, gas
+    // mass, stellar mass) of the family's members before the tile [0..4] and after it [5..9], the tile's largest
+    // M(<r) / max(r, softening) with that radius [10, 11] and, bound family, its largest M(<r) / r with radius and entry [12..14]
+    double *bscan;
 };
+#define BSCAN_W 16
 
 // Scratch of the tile-parallel build of one LARGE halo (several workgroups per halo, kernels k_g* of
 // halo_kernel.inc): append cursor of the selection, the sample sort's splitters / bucket fills / bucket groups, and

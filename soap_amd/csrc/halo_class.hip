@@ -94,6 +94,9 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
 extern "C" void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_bpartials, dim3((unsigned)std::min<long long>(ntiles, 256 * 8)), dim3(GRP), 0, stream, params, arena, ntiles, bpart);
+    // the tiles' cumulative weights and v_max candidates, behind the sums in the same allocation
+    double *bscan = bpart + ntiles * 2 * NACC;
+    hipLaunchKernelGGL(k_bscan, dim3((unsigned)std::min<long long>(ntiles, 256 * 16)), dim3(256), 0, stream, params, arena, ntiles, (const double *)bpart, bscan);
 }
 #else
 extern "C" void SOAP_CAT3(soap_launch_halo_, GCLASS, SOAP_VARIANT)(int groups, hipStream_t stream, const RunParams *params, SlabDev slab,
