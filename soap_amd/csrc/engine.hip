@@ -1209,7 +1209,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                               !(getenv("SOAP_ENGINE_LOAD_CLASSES") && atoi(getenv("SOAP_ENGINE_LOAD_CLASSES")) == 0);
     if (load_classes) {
         nb_small = std::min<long long>(nb_small, std::max<long long>(2048, (long long)(run_tau / 4.0e-7)));
-        nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / 6.0e-8)));
+        static const double medium_cost = getenv("SOAP_ENGINE_MEDIUM_COST") ? atof(getenv("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
+        nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / medium_cost)));
     }
     const auto t_host1 = std::chrono::steady_clock::now();
     // heaviest first inside every class (the reference orders by bound-particle count for the same
