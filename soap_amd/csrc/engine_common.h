@@ -152,6 +152,11 @@ struct GBuild {
     // their fills / starts / the starts of the bucket groups live in RunParams.gbins from bin_first on
     int nbin, bin_first;
     double bin_scale;    // bin = min(nbin - 1, int(r * bin_scale))
+    // cumulative mass of a slab of equal masses in closed form (k_gcumsum): entry q covers slab entries
+    // [cum_k[q], cum_k[q] + cum_cnt[q]) with cum[cum_k[q] + t - 1] = cum_x[q] + t cum_d[q]; the tiles fill them in (k_gpost)
+    int cum_ne;
+    int cum_k[72], cum_cnt[72];
+    double cum_x[72], cum_d[72];
     double splitter[GNBMAX];
     unsigned bcount[GNBMAX];
     int bstart[GNBMAX + 1];
