@@ -1500,9 +1500,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     // the selection holds at most est particles: tiles and bucket groups are sized by that
                     const long long e = std::max<long long>(est[rows[li]], 1);
                     const int nt = (int)((e + GTILE - 1) / GTILE);
-                    // beyond ~1e6 entries the sample of the sample sort is too thin for its GNBMAX buckets: uniform bins in
-                    // radius instead (~128 entries per bin), as many bucket groups as the entries need
-                    static const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 786432;
+                    // beyond a few 1e5 entries the sample of the sample sort (2048 entries for at most GNBMAX buckets: one or two
+                    // per bucket) is too thin -- a bucket outgrows its LDS block in one run in ten, which costs a millisecond of
+                    // rank sort: uniform bins in radius instead (~128 entries per bin), as many bucket groups as the entries need
+                    static const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
                     const bool giant_sort = e > giant_sort_limit;
                     const int ng = giant_sort ? (int)(e / 1024 + 2) : (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
                     const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / 256), 64) : 0;
