@@ -584,6 +584,8 @@ struct soap_engine {
         long long nh = 0;
     } cls[3];
     std::vector<long long> h_nrbound;
+    std::vector<unsigned long long> sort_ka, sort_kb;   // scratch of the classification sort (run)
+    std::vector<unsigned> sort_rows, sort_e32;
     // pipeline path: arena of per-halo slab slices, one record per halo
     SlabDev arena{};
     long long arena_cap = 0;
@@ -1220,19 +1222,28 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // LSD radix sort (3 x 11 bits) of the row numbers by estimate: rows enter in descending order and
         // the ascending result is read backwards, which gives descending estimates with ties in staged order
         const size_t n = (size_t)h->n_halo;
-        std::vector<unsigned> a(n), b(n), e32(n);
+        // keys and row numbers travel together (one sequential read per pass instead of a gather through the permutation),
+        // and a pass whose digit is zero in every key is skipped
+        // (scratch kept in the handle: fresh vectors of this size are fresh pages every call)
+        std::vector<unsigned long long> &ka = h->sort_ka, &kb = h->sort_kb;
+        std::vector<unsigned> &a = h->sort_rows, &e32 = h->sort_e32;
+        ka.resize(n); kb.resize(n); a.resize(n); e32.resize(n);
+        unsigned emax = 0u;
         for (size_t i = 0; i < n; i++) {
             e32[i] = (unsigned)std::min<long long>(std::max<long long>(est[i], 0), 0xffffffffLL);
-            a[i] = (unsigned)(n - 1 - i);
+            emax = std::max(emax, e32[i]);
         }
+        for (size_t i = 0; i < n; i++) ka[i] = ((unsigned long long)e32[n - 1 - i] << 32) | (unsigned long long)(n - 1 - i);
         for (int pass = 0; pass < 3; pass++) {
-            const int shift = 11 * pass;
+            const int shift = 32 + 11 * pass;
+            if (pass > 0 && (emax >> (11 * pass)) == 0u) break;
             size_t cnt[2049] = {0};
-            for (size_t i = 0; i < n; i++) cnt[((e32[a[i]] >> shift) & 2047u) + 1]++;
+            for (size_t i = 0; i < n; i++) cnt[((ka[i] >> shift) & 2047ull) + 1]++;
             for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
-            for (size_t i = 0; i < n; i++) b[cnt[(e32[a[i]] >> shift) & 2047u]++] = a[i];
-            a.swap(b);
+            for (size_t i = 0; i < n; i++) kb[cnt[(ka[i] >> shift) & 2047ull]++] = ka[i];
+            ka.swap(kb);
         }
+        for (size_t r = 0; r < n; r++) a[r] = (unsigned)(ka[r] & 0xffffffffull);
         for (size_t r = n; r-- > 0;) {
             const unsigned i = a[r];
             const long long nb = e32[i];
