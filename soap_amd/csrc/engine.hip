@@ -256,7 +256,7 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
 // threads store to consecutive addresses -- four coalesced streams instead of four scattered 8-byte stores
 // per particle.  Launched with the grid of k_cellid (same particles per block iteration).
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
-                              unsigned *sort_idx, const double *pos, double *x, double *y, double *z,
+                              const double *pos, double *x, double *y, double *z,
                               Pay *pay, const double *vel, const double *mass, const int *g32, const long long *g64,
                               const long long *fof, int nu) {
     __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
@@ -313,7 +313,6 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
         if (threadIdx.x < s_total) {
             const unsigned q = s_p[threadIdx.x];
             const unsigned io = s_i[threadIdx.x];
-            sort_idx[q] = io;
             x[q] = s_x[threadIdx.x]; y[q] = s_y[threadIdx.x]; z[q] = s_z[threadIdx.x];
             // the payload record of the particle (read from the block's own window of the caller's arrays)
             Pay r;
@@ -325,7 +324,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
                 r.grnr = g64 ? g64[io] : (long long)g32[io];
                 r.fof = fof[io];
             }
-            r.pad_ = 0.0;
+            r.orig = (long long)io;   // (instead of an index array of its own: one scattered 4-byte store less per particle)
             const double2 *w = (const double2 *)&r;
 #pragma unroll
             for (int k = 0; k < 5; k++) s_pay[5 * threadIdx.x + k] = w[k];
@@ -459,13 +458,13 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
         double r = sqrt((wx * wx + wy * wy) + wz * wz);
         bool in = strict ? (r < R) : (r <= R);
         if (in && bound_only) {
-            const unsigned o = T.orig[p];
+            const long long o = T.pay[p].orig;
             long long g = T.grnr64 ? T.grnr64p[o] : (long long)T.grnr32[o];
             in = (g == hindex);
         }
         if (in) {
             unsigned s = atomicAdd(count, 1u);
-            if ((long long)s < cap) out[s] = (long long)T.orig[p];
+            if ((long long)s < cap) out[s] = T.pay[p].orig;
         }
     }
 }
@@ -903,7 +902,6 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         HIPCHECK(grab((void **)&d_cell, (size_t)n * 4, scratch));
         HIPCHECK(grab((void **)&d_count, (size_t)ncell * 4, scratch));
         HIPCHECK(grab((void **)&d_rank, (size_t)n * 4, scratch));
-        HIPCHECK(pool.alloc((void **)&T.orig, (size_t)n * 4));
         HIPCHECK(pool.alloc((void **)&T.cell_offset, (size_t)(ncell + 1) * 4));
         HIPCHECK(hipMemsetAsync(d_count, 0, (size_t)ncell * 4, st));
         MeshGeom g;
@@ -935,7 +933,7 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         }
         HIPCHECK(hipEventCreate(&ev2));
         HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
-        hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset, T.orig,
+        hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
                            dpos, T.x, T.y, T.z, T.pay, T.vel, T.mass, T.g32, T.g64, T.fof, nu ? 1 : 0);
         HIPCHECK(hipEventRecord(ev2, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -1824,7 +1822,7 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t ts, double r
     HIPCHECK(hipMemcpy(&hindex, h->d_index + row, 8, hipMemcpyDeviceToHost));
     TypeDev D;
     memset(&D, 0, sizeof(D));
-    D.n = T.n; D.grnr64 = T.grnr64; D.x = T.x; D.y = T.y; D.z = T.z; D.grnr32 = T.g32; D.grnr64p = T.g64; D.orig = T.orig;
+    D.n = T.n; D.grnr64 = T.grnr64; D.x = T.x; D.y = T.y; D.z = T.z; D.grnr32 = T.g32; D.grnr64p = T.g64; D.pay = T.pay;
     unsigned *d_cnt;
     long long *d_out = nullptr;
     HIPCHECK(hipMalloc((void **)&d_cnt, 4));

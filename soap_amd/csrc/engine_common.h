@@ -48,7 +48,7 @@ struct alignas(16) Pay {
     double vx, vy, vz, m;
     long long grnr, fof;
     double x, y, z;
-    double pad_;
+    long long orig;     // index of the particle in the caller's arrays (what the membership probe reports)
 };
 static_assert(sizeof(Pay) == 80, "five 16-byte words");
 
