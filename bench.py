@@ -416,8 +416,8 @@ def main():
             except (OSError, ValueError, KeyError):
                 continue
         # the placement pass: coordinates read (24 B), cell id + rank read back (8 B), coordinates written in cell order (24 B),
-        # permutation (4 B); velocities / masses / ids read (44 B) and the 80-byte payload record written
-        b_reorder = (wl["n_part"] if world == 1 else n_region) * (24 + 8 + 24 + 4 + 44 + 80)
+        # velocities / masses / ids read (44 B) and the 80-byte payload record written (the original index travels in it)
+        b_reorder = (wl["n_part"] if world == 1 else n_region) * (24 + 8 + 24 + 44 + 80)
         line = {
             "metric": "particle_aperture_evals_per_s",
             "value": evals_all * npasses / dt,
@@ -465,7 +465,7 @@ def main():
                 "achieved": b_reorder / (float(np.mean(ms_reorder)) * 1e-3) / 1e9,
                 "unit": "GB/s", "algorithmic_bytes": b_reorder,
                 "note": "bytes the placement pass moves per particle: coordinates read (24 B) and written in cell order (24 B), "
-                        "permutation (4 B), cell id + rank read back (8 B), velocities / masses / ids read (44 B) and the "
+                        "cell id + rank read back (8 B), velocities / masses / ids read (44 B) and the "
                         "80-byte payload record written",
             },
             "generation_s": t_gen,
