@@ -13,7 +13,7 @@
 #define GCH 1024
 #define SORT_NBMAX 64
 #define GLB 4
-#define SCAN_E 4           // consecutive particles per lane in the radial scan (fused_scan)
+#define SCAN_E 2           // consecutive particles per lane in the radial scan (fused_scan): most halos of this class fit one or two blocks anyway (4: 13.9 ms for the class alone on C3, 2: 13.6, 1: 13.6)
 #define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #elif GCLASS == 256
