@@ -355,6 +355,8 @@ SOAP_DECL_LAUNCH(soap_launch_halo_1024n); SOAP_DECL_LAUNCH(soap_launch_halo_1024
 // pipeline stages (GMODE 1: build, GMODE 2: property passes) and the radius loop with lanes = halos (stage_a.hip)
 SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b); SOAP_DECL_LAUNCH(soap_launch_halo_1024b);
 SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
+// the small-halo class (small_halo.hip): one wavefront per halo, slab in LDS; variants by slab entries and chunk content
+void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
@@ -582,6 +584,7 @@ struct soap_engine {
         double ms = 0.0;
         long long nh = 0;
     } cls[3];
+    Class small;   // the small-halo class (no slab: its halos live in LDS)
     std::vector<long long> h_nrbound;
     std::vector<unsigned long long> sort_ka, sort_kb;   // scratch of the classification sort (run)
     std::vector<unsigned> sort_rows, sort_e32;
@@ -604,7 +607,7 @@ struct soap_engine {
     hipEvent_t ev_p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double ms_build = 0, ms_stage_a = 0, ms_stage_b = 0;
     int n_passes = 0;
-    long long n_pipeline = 0, n_single = 0;
+    long long n_pipeline = 0, n_single = 0, n_small_escalated = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -739,6 +742,14 @@ static int32_t create_resources(soap_engine *h) {
         for (int q = 0; q < 2; q++) { HIPCHECK(hipEventCreate(&h->cls[k].pstart[q])); HIPCHECK(hipEventCreate(&h->cls[k].pdone[q])); }
         HIPCHECK(hipMalloc((void **)&h->cls[k].d_queue, sizeof(unsigned)));
     }
+    {
+        // the small-halo class shares the priority level of the wavefront class
+        if (h->own_streams) HIPCHECK(hipStreamCreateWithPriority(&h->small.stream, hipStreamNonBlocking, prio_least));
+        else HIPCHECK(hipStreamCreate(&h->small.stream));
+        HIPCHECK(hipEventCreate(&h->small.done));
+        HIPCHECK(hipEventCreate(&h->small.start));
+        HIPCHECK(hipMalloc((void **)&h->small.d_queue, sizeof(unsigned)));
+    }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
     for (int k = 0; k < 6; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
@@ -776,6 +787,11 @@ int32_t soap_engine_destroy(soap_engine *h) {
         for (int q = 0; q < 2; q++) { if (h->cls[k].pstart[q]) (void)hipEventDestroy(h->cls[k].pstart[q]); if (h->cls[k].pdone[q]) (void)hipEventDestroy(h->cls[k].pdone[q]); }
         if (h->cls[k].stream) (void)hipStreamDestroy(h->cls[k].stream);
     }
+    if (h->small.d_queue) (void)hipFree(h->small.d_queue);
+    if (h->small.d_todo) (void)hipFree(h->small.d_todo);
+    if (h->small.done) (void)hipEventDestroy(h->small.done);
+    if (h->small.start) (void)hipEventDestroy(h->small.start);
+    if (h->small.stream) (void)hipStreamDestroy(h->small.stream);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_calcs) (void)hipFree(h->d_calcs);
     if (h->d_coloff) (void)hipFree(h->d_coloff);
@@ -1248,6 +1264,32 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
         }
     }
+    // ---- the small-halo class (small_halo.hip): halos of the wavefront class whose sorted superset is expected to fit SMALL_NS
+    // slab entries in LDS.  The superset of a halo that is not inside a larger one's envelope holds ~1.5 x its bound
+    // particles (C3: 1.39 / 1.52 / 1.69 at the 10th / 50th / 90th percentile); one that does not fit after all comes back
+    // with SOAP_HALO_FATAL_SLAB_OVERFLOW and is done by the wavefront class in the next pass.  Runs that need what the class
+    // leaves out stay on the general path altogether.
+    std::vector<int> todo_small;
+    {
+        bool small_ok = !want_inertia && !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
+                        P.profile != 1 && h->cfg.slab_capacity <= 0;
+        for (int c = 0; c < n_calcs; c++)
+            if (calcs[c].kind == SOAP_CALC_PROJECTED || (calcs[c].flags & SOAP_CALC_FLAG_ROTATION)) small_ok = false;
+        int small_mode = 1;
+        { const char *e = getenv("SOAP_ENGINE_SMALL"); if (e) small_mode = atoi(e); }
+        if (small_ok && small_mode != 0) {
+            const long long small_ns = 128;
+            double small_factor = 1.6;
+            { const char *e = getenv("SOAP_ENGINE_SMALL_FACTOR"); if (e) small_factor = atof(e); }
+            std::vector<int> rest;
+            rest.reserve(todo[0].size());
+            for (int i : todo[0]) {
+                const bool take = small_mode == 2 || (double)h->h_nrbound[i] * small_factor + 4.0 <= (double)small_ns;   // (mode 2: every halo of the class tries, test hook)
+                (take ? todo_small : rest).push_back(i);
+            }
+            todo[0].swap(rest);
+        }
+    }
     TRACE("run: classified");
     const auto t_host2 = std::chrono::steady_clock::now();
     h->ms_host_setup = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
@@ -1298,6 +1340,28 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         return 0;
     };
+    int groups_small = 256 * 11;   // (14 KB of LDS per wave: eleven waves per CU)
+    { const char *e = getenv("SOAP_ENGINE_GS"); if (e) groups_small = atoi(e); }
+    auto launch_small = [&](std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
+        if (list.empty()) return 0;
+        soap_engine::Class &C = h->small;
+        const long long nt = (long long)list.size();
+        if (C.todo_cap < nt) {
+            if (C.d_todo) (void)hipFree(C.d_todo);
+            C.todo_cap = std::max<long long>(nt, h->n_halo);
+            HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
+        }
+        hipStream_t cs = C.stream;
+        HIPCHECK(hipStreamWaitEvent(cs, after, 0));
+        HIPCHECK(hipMemcpyAsync(C.d_todo, list.data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+        HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+        HIPCHECK(hipEventRecord(C.start, cs));
+        C.nh += nt;
+        soap_launch_small_128d((int)std::min<long long>(groups_small, nt), cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        HIPCHECK(hipEventRecord(C.done, cs));
+        if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+        return 0;
+    };
     bool pipeline = !want_inertia && !P.has_nu && !P.literal && !want_property_radius;
     // SOAP_ENGINE_PIPELINE: 0 the single-kernel path for every halo; 1 the mix described below; 2 every halo through the
     // pipeline; 3 (the default) the GIANTS through the pipeline -- halos whose sphere holds more than nb_giant candidates
@@ -1330,6 +1394,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipEventRecord(h->ev_p[0], st));
     TRACE("run: ev recorded");
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
+    h->small.ms = 0.0; h->small.nh = 0; h->n_small_escalated = 0;
     // Hybrid (SOAP_ENGINE_PIPELINE=1): the pipeline takes the halos of the wavefront class -- nine in ten, and what saturates the GPU on
     // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
     // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
@@ -1676,7 +1741,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         h->pool.release(d_state, n * 4); h->pool.release(d_rbuild, n * 8);
     }
     TRACE("run: single-kernel part");
-    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size());
+    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small.size());
     int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
@@ -1706,7 +1771,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (only_class >= 0) for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear();   // diagnostics
         for (int k = 0; k < 3; k++) any = any || !todo[k].empty();
         {
-            int rc = launch_single(todo, h->ev0, true);
+            // (the small-halo class first: its waves leave room for the persistent groups of the other classes, not the other way round)
+            int rc = launch_small(todo_small, h->ev0, true);
+            if (rc) return rc;
+            any = any || !todo_small.empty();
+            rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
         }
         if (pass == 0) {
@@ -1724,6 +1793,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemcpyAsync(status.data(), h->d_status, (size_t)h->n_halo * 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         for (int k = 0; k < 3; k++) HIPCHECK(hipStreamSynchronize(h->cls[k].stream));
+        HIPCHECK(hipStreamSynchronize(h->small.stream));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(-101, std::string("halo kernel: ") + hipGetErrorString(le));
         float ms = 0;
@@ -1734,6 +1804,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // escalate halos whose search sphere did not fit their class' slab
         std::vector<int> next[3];
         bool grow_top = false;
+        if (!todo_small.empty()) {
+            float m2 = 0;
+            (void)hipEventElapsedTime(&m2, h->small.start, h->small.done);
+            h->small.ms += m2;
+            for (int i : todo_small)
+                if (status[i] == SOAP_HALO_FATAL_SLAB_OVERFLOW) next[0].push_back(i);
+            h->n_small_escalated += (long long)next[0].size();
+            todo_small.clear();
+        }
         for (int k = 0; k < 3; k++)
             for (int i : todo[k])
                 if (status[i] == SOAP_HALO_FATAL_SLAB_OVERFLOW) {
@@ -1763,6 +1842,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->cls[k].done, h->cls[k].stream));
             HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
         }
+        HIPCHECK(hipEventRecord(h->small.done, h->small.stream));
+        HIPCHECK(hipStreamWaitEvent(st, h->small.done, 0));
         HIPCHECK(hipEventRecord(h->ev1, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -1860,6 +1941,9 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "halo_wave")) return h->cls[0].ms;
     if (!strcmp(name, "halo_wg256")) return h->cls[1].ms;
     if (!strcmp(name, "halo_wg1024")) return h->cls[2].ms;
+    if (!strcmp(name, "halo_small")) return h->small.ms;
+    if (!strcmp(name, "n_small")) return (double)h->small.nh;
+    if (!strcmp(name, "n_small_escalated")) return (double)h->n_small_escalated;
     if (!strcmp(name, "n_wave")) return (double)h->cls[0].nh;
     if (!strcmp(name, "n_wg256")) return (double)h->cls[1].nh;
     if (!strcmp(name, "n_wg1024")) return (double)h->cls[2].nh;

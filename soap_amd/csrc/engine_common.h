@@ -393,6 +393,34 @@ enum {
 
 #define GAS __attribute__((address_space(1)))
 
+// ---- views with pointers typed as global memory (address_space(1): global_load/store instead of flat) ----
+struct TypeG {   // same layout as TypeDev, pointers typed as global
+    long long n;
+    int res;
+    int grnr64;
+    const GAS double *x, *y, *z;
+    const GAS double *vel, *mass;
+    const GAS int *grnr32;
+    const GAS long long *grnr64p;
+    const GAS long long *fof;
+    const GAS unsigned *orig;
+    const GAS unsigned *cell_offset;
+    const GAS Pay *pay;
+    double pos_min[3], pos_max[3], cell_size[3];
+};
+static_assert(sizeof(TypeG) == sizeof(TypeDev), "TypeG mirrors TypeDev");
+
+// one payload record from global memory (field by field: the compiler merges them into 16-byte loads)
+SOAP_DEV Pay load_pay(const GAS Pay *p) {
+    const GAS double *d = (const GAS double *)p;
+    const GAS long long *l = (const GAS long long *)p;
+    Pay q;
+    q.vx = d[0]; q.vy = d[1]; q.vz = d[2]; q.m = d[3];
+    q.grnr = l[4]; q.fof = l[5];
+    q.x = d[6]; q.y = d[7]; q.z = d[8]; q.orig = 0;   // (the property passes have no use for the original index)
+    return q;
+}
+
 struct Mask256 {   // 256-bit cell mask held in registers (no dynamically indexed private array)
     unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     __device__ __forceinline__ void set_range(int lo, int hi) {   // bits [lo, hi]

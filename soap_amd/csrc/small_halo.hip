@@ -1,0 +1,1331 @@
+// The small-halo class: ONE WAVEFRONT per halo, the halo's slab resident in LDS from the selection to the last property.
+//
+// Nine halos in ten of a chunk hold a few hundred particles in their final search sphere (C3: 57 % below 128, 77 % below
+// 256, 87 % below 512), and what they cost in the thread-group classes of halo_kernel.inc is not arithmetic but the
+// ~100 dependent round trips to a slab in global memory that one wavefront with 256 registers (two per SIMD) waits for.
+// Here the whole per-halo state is SNS slab entries in LDS (81 bytes each) plus registers:
+//
+//   select     candidate cells exactly as shared_mesh.py:146-179, rows streamed with SEL_UT tiles in flight; the test is the
+//              minimum-image r^2 <= R^2 of shared_mesh.py:183-194; only the packed index of a selected particle is kept
+//   gather     one payload record per selected particle (all loads of the wave in flight together): wrapped offsets
+//              (halo_tasks.py:113-117), radius, minimum-image r^2, velocity, mass, membership bits
+//   sort       (r, index) bitonic network in REGISTERS (entry i of the slab belongs to lane i mod 64), then the columns are
+//              permuted into sorted order through LDS
+//   cumsum     the sequential fp64 chain of numpy.cumsum (SO_properties.py:400) by one lane over LDS
+//   radius loop / stage A    halo_tasks.py:74-187 with lanes = calculations, the same decisions as k_halo of halo_kernel.inc
+//              (shared code: halo_so_eval.inc); the spheres of the rounds are counted with ballots over the r^2 registers
+//   stage B    prefix moments from one inclusive wave scan per block of 64 entries, the radial scan (v_max, half-mass radii),
+//              spin, dark matter flow rates; finalisation with lanes = calculations (shared code: halo_finalize.inc)
+//
+// No scratch, no slab traffic to HBM: what the kernel reads is 24 B per candidate and 80 B per selected particle, what it
+// writes is the halo's row of the result table.  A halo whose sphere outgrows SNS entries -- or that needs something this
+// kernel leaves to the general path (radius ties, neutrinos, inertia tensors, ...) -- comes back with
+// SOAP_HALO_FATAL_SLAB_OVERFLOW and is done by the wavefront class of halo_kernel.inc (engine.hip escalates it).
+//
+// Compiled once per variant: -DSNS=<slab entries> -DSHYDRO=<0: dark matter only chunk, 1: gas / stars / black holes too>.
+#include "engine_common.h"
+
+#ifndef SNS
+#define SNS 128
+#endif
+#ifndef SHYDRO
+#define SHYDRO 0
+#endif
+#define SE (SNS / 64)          // slab entries per lane: entry i belongs to lane i & 63, register slot i >> 6
+#define SPREFB 12              // calculations whose prefix moments are finalised together
+#if SHYDRO
+#define SMOM A_NSUM
+#define SNHM NHM
+#else
+#define SMOM (A_RMAX + 1)
+#define SNHM 2
+#endif
+#ifndef SEL_UT
+#define SEL_UT 4               // candidate tiles in flight per trip of the selection
+#endif
+#ifndef SWPE
+#define SWPE 3
+#endif
+
+#define CAS __attribute__((address_space(4)))   // constant memory: uniform addresses become scalar loads
+
+#define SOAP_CAT4_(a, b, c, d) a##b##c##d
+#define SOAP_CAT4(a, b, c, d) SOAP_CAT4_(a, b, c, d)
+#if SHYDRO
+#define SVAR h
+#else
+#define SVAR d
+#endif
+
+namespace {
+
+
+struct SmallWave {
+    // the slab, sorted by radius once it is built
+    double r[SNS], cum[SNS], m[SNS], dx[SNS], dy[SNS], dz[SNS], vx[SNS], vy[SNS], vz[SNS];
+    unsigned pidx[SNS];
+    unsigned char flags[SNS];
+    // stage B
+    double prefc[SPREFB][SMOM];   // prefix moments of up to SPREFB calculations
+    int bnd[MAXCALC];             // prefix lengths of a family's calculations in ascending order
+    // per-halo context, named as in halo_kernel.inc (the shared includes read them through g_S)
+    double c[3], L, shift[3];
+    double nu_density, a, mpc, mpc20, G_eff;
+    int hydro, has_nu;
+    unsigned ticket;   // queue position of the halo the wave is working on
+#ifdef SMALL_CHECK
+    unsigned long long *dbg;
+#endif
+};
+
+__shared__ SmallWave g_W;
+#ifdef SMALL_CHECK
+// diagnostic build: a violated bound is reported through P.phase[16 + code] (largest offending value + 1) and the access skipped
+#define SCHECK(cond, code, val) ((cond) ? true : (atomicMax((unsigned long long *)&g_W.dbg[16 + (code)], (unsigned long long)(val) + 1ull), false))
+#else
+#define SCHECK(cond, code, val) true
+#endif
+#define g_S g_W
+#define LANE ((int)(threadIdx.x & 63))
+
+// LDS traffic between the lanes of ONE wave: its LDS instructions execute in order, so only the compiler has to be kept
+// from moving accesses across the hand-over (no s_waitcnt on outstanding global loads, unlike a workgroup-scope fence)
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Cross-lane reads.  v_readlane / v_readfirstlane of a CONSTANT fold to that constant -- rightly so when every lane holds it,
+// but the compiler also applies the fold along single edges of a lane-dependent branch ("in the lanes that skipped
+// `if (LANE == 0) x = ...`, x is 0, hence readfirstlane(x) is 0") and then threads later uniform branches per lane: the
+// queue loop of this kernel was compiled into an exit that only lane 0 took.  Every value read across lanes therefore
+// passes an empty asm first, after which nothing is known about it; values that exist in one lane only are better not
+// created at all (LDS hand-over, or the same arithmetic in every lane).  And: these reads belong in code that EVERY lane
+// executes -- inside a lane-dependent branch the asm copies the value in that branch's lanes only.
+SOAP_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+SOAP_DEV int rl(int v, int lane) { return __builtin_amdgcn_readlane(opaque(v), lane); }
+SOAP_DEV double rl64(double v, int lane) {
+    const int lo = rl(__double2loint(v), lane), hi = rl(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+SOAP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(opaque(v)); }   // a value that is the same in every lane, made known to the compiler as such
+SOAP_DEV double uni(double v) {
+    const int lo = uni(__double2loint(v)), hi = uni(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+SOAP_DEV long long uni(long long v) {
+    const unsigned lo = (unsigned)uni((int)(unsigned)v), hi = (unsigned)uni((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// enclosed density of slab entry i as materialize() of halo_kernel.inc tabulates it (SO_properties.py:404-406, :420)
+SOAP_DEV double small_dens(int i) {
+    const double nuK = ((g_S.nu_density * 4.0) / 3.0) * M_PI;
+    const double K43 = (4.0 / 3.0) * M_PI;
+    const double r3 = cube(g_W.r[i]);
+    return (g_W.cum[i] + nuK * r3) / (K43 * r3);
+}
+#define SV_R(i) g_W.r[i]
+#define SV_CUM(i) g_W.cum[i]
+#define SV_DENS(i) small_dens(i)
+#define RES_OK 0
+#define RES_TOO_SMALL 1
+#include "halo_so_eval.inc"
+#define FZ_PARK_ROT(c, d, vg, vs) { }   // (no rotation pass in this class: engine.hip keeps such runs on the general path)
+// log10 / 10**x of the concentration as real calls: inlined, the two library routines hold ~100 registers at their peak and push
+// the kernel's long-lived values into scratch
+#ifdef SMALL_INLINE_MATH
+__device__ __forceinline__ double small_log10(double x) { return log10(x); }
+__device__ __forceinline__ double small_exp10(double x) { return exp10(x); }
+#else
+__device__ __attribute__((noinline)) double small_log10(double x) { return log10(x); }
+__device__ __attribute__((noinline)) double small_exp10(double x) { return exp10(x); }
+#endif
+#define FZ_LOG10(x) small_log10(x)
+#define FZ_EXP10(x) small_exp10(x)
+#define FZ_MOM const volatile double *   // (the moments are read from LDS where they are used: hoisted, they would occupy 80 registers)
+#include "halo_finalize.inc"
+
+// ---- 256-bit cell masks: runs of set bits without a loop over the cells ------------------------------------------------
+SOAP_DEV unsigned long long mask_word(const Mask256 &m, int k) { return k == 0 ? m.w0 : (k == 1 ? m.w1 : (k == 2 ? m.w2 : m.w3)); }
+// first set (want = 1) or clear (want = 0) bit at position >= from, or 256
+SOAP_DEV int mask_next(const Mask256 &m, int from, int want) {
+    for (int k = from >> 6; k < 4; k++) {
+        unsigned long long w = mask_word(m, k);
+        if (!want) w = ~w;
+        if (k == (from >> 6)) { const int sh = from & 63; w = (w >> sh) << sh; }
+        if (w) return 64 * k + __ffsll((long long)w) - 1;
+    }
+    return 256;
+}
+
+// candidate cells of type `T` along the three axes for a sphere of radius R about the halo centre (shared_mesh.py:146-179):
+// lane d < 3 works on axis d, every lane gets all three masks
+SOAP_DEV void cell_masks(const CAS TypeDev &T, double R, Mask256 &mx, Mask256 &my, Mask256 &mz) {
+    const int d = LANE < 2 ? LANE : 2;
+    const double pmin = d == 0 ? T.pos_min[0] : (d == 1 ? T.pos_min[1] : T.pos_min[2]);
+    const double pmax = d == 0 ? T.pos_max[0] : (d == 1 ? T.pos_max[1] : T.pos_max[2]);
+    const double csz = d == 0 ? T.cell_size[0] : (d == 1 ? T.cell_size[1] : T.cell_size[2]);
+    const double c = d == 0 ? g_W.c[0] : (d == 1 ? g_W.c[1] : g_W.c[2]), L = g_W.L;
+    const int res = T.res;
+    Mask256 mk;
+    int min_copy = 0, max_copy = 0, guard = 0;
+    while (c + (double)(min_copy - 1) * L + R >= pmin && guard++ < 4096) min_copy--;
+    guard = 0;
+    while (c + (double)(max_copy + 1) * L - R <= pmax && guard++ < 4096) max_copy++;
+    for (int cp = min_copy; cp <= max_copy; cp++) {
+        const double lo = fmax(pmin, c + (double)cp * L - R);
+        const double hi = fmin(pmax, c + (double)cp * L + R);
+        const double qlo = floor((lo - pmin) / csz);
+        const double qhi = floor((hi - pmin) / csz);
+        const int ilo = qlo < 0.0 ? 0 : (qlo > 1e9 ? 1000000000 : (int)qlo);
+        const int ihi = qhi < -1.0 ? -1 : (qhi > (double)(res - 1) ? res - 1 : (int)qhi);
+        if (ilo <= ihi) mk.set_range(ilo, ihi);
+    }
+#define BC64(w, l) ((unsigned long long)(unsigned)rl((int)(unsigned)(w), l) | ((unsigned long long)(unsigned)rl((int)(unsigned)((w) >> 32), l) << 32))
+    mx.w0 = BC64(mk.w0, 0); mx.w1 = BC64(mk.w1, 0); mx.w2 = BC64(mk.w2, 0); mx.w3 = BC64(mk.w3, 0);
+    my.w0 = BC64(mk.w0, 1); my.w1 = BC64(mk.w1, 1); my.w2 = BC64(mk.w2, 1); my.w3 = BC64(mk.w3, 1);
+    mz.w0 = BC64(mk.w0, 2); mz.w1 = BC64(mk.w1, 2); mz.w2 = BC64(mk.w2, 2); mz.w3 = BC64(mk.w3, 2);
+#undef BC64
+}
+
+#define SMAXRUN 6
+// runs of set bits of the x mask (one per periodic copy of the sphere), 8 bits per run in two words; beyond SMAXRUN the
+// last run swallows the rest (a superset of the cells is still exact: the r^2 test decides)
+SOAP_DEV int small_x_runs(const Mask256 &mx, int res, unsigned long long &lo_pack, unsigned long long &hi_pack) {
+    int nrun = 0;
+    lo_pack = 0ull; hi_pack = 0ull;
+    int i0 = mask_next(mx, 0, 1);
+    while (i0 < res && nrun < SMAXRUN) {
+        int i1 = mask_next(mx, i0, 0) - 1;
+        if (i1 > res - 1) i1 = res - 1;
+        if (nrun == SMAXRUN - 1) {
+            for (int q = res - 1; q > i1; q--) if (mx.get(q)) { i1 = q; break; }
+        }
+        lo_pack |= (unsigned long long)i0 << (8 * nrun);
+        hi_pack |= (unsigned long long)i1 << (8 * nrun);
+        nrun++;
+        i0 = mask_next(mx, i1 + 1, 1);
+    }
+    return nrun;
+}
+SOAP_DEV int pick_run(unsigned long long pack, int r) { return (int)((pack >> (8 * r)) & 0xffull); }
+
+// Particles with minimum-image r^2 <= R^2 (shared_mesh.py:183-194): their packed indices to g_W.pidx[0, n).  Returns n,
+// or -1 as soon as the sphere is known not to fit the slab.
+__device__ __forceinline__ int small_select(const CAS RunParams &P, double R) {
+    const double R2 = R * R;
+    const double cx = g_W.c[0], cy = g_W.c[1], cz = g_W.c[2], L = g_W.L;
+    int nsel = 0;
+#pragma unroll 1
+    for (int ts = 0; ts < SOAP_NTYPES; ts++) {
+        const CAS TypeDev &T = P.t[ts];
+        if (T.n == 0) continue;
+        const int res = T.res;
+        Mask256 mx, my, mz;
+        cell_masks(T, R, mx, my, mz);
+        unsigned long long run_lo, run_hi;
+        const int nrun = small_x_runs(mx, res, run_lo, run_hi);
+        const int nk = mz.count(), nj = my.count();
+        const int ntrip = nk * nj * nrun;
+        const GAS double *tx = (const GAS double *)T.x, *ty = (const GAS double *)T.y, *tz = (const GAS double *)T.z;
+        const GAS unsigned *toff = (const GAS unsigned *)T.cell_offset;
+#pragma unroll 1
+        for (int t0 = 0; t0 < ntrip; t0 += 64) {
+            unsigned mybeg = 0, myend = 0;
+            {
+                const int tl = t0 + LANE;
+                if (tl < ntrip) {
+                    const int rr = tl % nrun, pj = (tl / nrun) % nj, pk = tl / (nrun * nj);
+                    const int k = mz.nth(pk), j = my.nth(pj);
+                    const long long rowbase = (long long)res * j + (long long)res * res * k;
+                    if (SCHECK(k >= 0 && k < res && j >= 0 && j < res && pick_run(run_hi, rr) < res && pick_run(run_lo, rr) <= pick_run(run_hi, rr), 1, rowbase + pick_run(run_hi, rr))) {
+                    mybeg = toff[rowbase + pick_run(run_lo, rr)];
+                    myend = toff[rowbase + pick_run(run_hi, rr) + 1];
+                    }
+                    (void)SCHECK((long long)myend <= T.n && mybeg <= myend, 2, myend);
+                    if ((long long)myend > T.n || mybeg > myend) { mybeg = 0; myend = 0; }
+                }
+            }
+            const int cnt = ntrip - t0 < 64 ? ntrip - t0 : 64;
+#pragma unroll 1
+            for (int q = 0; q < cnt; q++) {
+                const unsigned beg = (unsigned)rl((int)mybeg, q);
+                const unsigned end = (unsigned)rl((int)myend, q);
+#pragma unroll 1
+                for (unsigned pb = beg; pb < end; pb += SEL_UT * 64) {
+                    unsigned pp[SEL_UT];
+                    double xx[SEL_UT], yy[SEL_UT], zz[SEL_UT];
+#pragma unroll
+                    for (int u = 0; u < SEL_UT; u++) {
+                        pp[u] = pb + u * 64 + LANE;
+                        xx[u] = yy[u] = zz[u] = 0.0;
+                        if (pp[u] < end) { xx[u] = tx[pp[u]]; yy[u] = ty[pp[u]]; zz[u] = tz[pp[u]]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < SEL_UT; u++) {
+                        bool sel = false;
+                        if (pp[u] < end) {
+                            const double ax = min_image(xx[u], cx, L), ay = min_image(yy[u], cy, L), az = min_image(zz[u], cz, L);
+                            const double r2 = (ax * ax + ay * ay) + az * az;
+                            sel = r2 <= R2;
+                        }
+                        const unsigned long long b = __ballot(sel);
+                        if (b) {
+                            const int slot = nsel + __popcll(b & ((1ull << LANE) - 1ull));
+                            if (sel && slot < SNS) g_W.pidx[slot] = ((unsigned)ts << PIDX_BITS) | pp[u];
+                            nsel += __popcll(b);
+                        }
+                    }
+                    if (nsel > SNS) return -1;
+                }
+            }
+        }
+    }
+    return nsel;
+}
+
+// number of particles in the mesh cells a sphere of radius R overlaps (n_cand of the particle-aperture-evaluation
+// accounting); no particle data is touched
+__device__ __forceinline__ long long small_count_candidates(const CAS RunParams &P, double R) {
+    double tot = 0.0;
+#pragma unroll 1
+    for (int ts = 0; ts < NT_ALL; ts++) {
+        const CAS TypeDev &T = P.t[ts];
+        if (T.n == 0) continue;
+        const int res = T.res;
+        Mask256 mx, my, mz;
+        cell_masks(T, R, mx, my, mz);
+        unsigned long long run_lo, run_hi;
+        const int nrun = small_x_runs(mx, res, run_lo, run_hi);
+        const int nk = mz.count(), nj = my.count();
+        const int ntrip = nk * nj * nrun;
+        const GAS unsigned *toff = (const GAS unsigned *)T.cell_offset;
+        for (int tl = LANE; tl < ntrip; tl += 64) {
+            const int rr = tl % nrun, pj = (tl / nrun) % nj, pk = tl / (nrun * nj);
+            const int k = mz.nth(pk), j = my.nth(pj);
+            const long long rowbase = (long long)res * j + (long long)res * res * k;
+            tot += (double)(toff[rowbase + pick_run(run_hi, rr) + 1] - toff[rowbase + pick_run(run_lo, rr)]);
+        }
+    }
+    return (long long)wave_sum(tot);   // (integers below 2^53: exact)
+}
+
+// ---- (key, index) sort in registers ------------------------------------------------------------------------------------
+// Element i = 64 e + lane of a bitonic network over npad = 2^lg elements: key k[e] (radius), v[e] (packed particle index,
+// the tie-break: pairs are distinct) and s[e] (a payload that travels along).  Stages whose partner lies in another lane
+// exchange through the cross-lane network (ds_bpermute: no LDS memory involved), the others stay in the lane's registers.
+SOAP_DEV void sort_exchange(double &k, unsigned &v, unsigned &s, int j, bool want_min) {
+    const int lo = __double2loint(k), hi = __double2hiint(k);
+    const int plo = __shfl_xor(lo, j, 64), phi = __shfl_xor(hi, j, 64);
+    const unsigned pv = (unsigned)__shfl_xor((int)v, j, 64), ps = (unsigned)__shfl_xor((int)s, j, 64);
+    const double pk = __hiloint2double(phi, plo);
+    const bool partner_less = pk < k || (pk == k && pv < v);
+    const bool take = want_min ? partner_less : !partner_less;
+    // (equal pairs are padding: taking or keeping is the same)
+    if (take && !(pk == k && pv == v)) { k = pk; v = pv; s = ps; }
+}
+__device__ __forceinline__ void small_sort(double (&k)[SE], unsigned (&v)[SE], unsigned (&s)[SE], int lg) {
+    const int ne = lg <= 6 ? 1 : (1 << (lg - 6));   // register slots that hold elements below npad
+#pragma unroll 1
+    for (int p = 1; p <= lg; p++) {
+        const int kk = 1 << p;
+#pragma unroll 1
+        for (int jb = p - 1; jb >= 0; jb--) {
+            const int j = 1 << jb;
+            if (jb < 6) {
+#pragma unroll
+                for (int e = 0; e < SE; e++) {
+                    if (e >= ne) continue;
+                    const int i = 64 * e + LANE;
+                    const bool asc = (i & kk) == 0, lower = (i & j) == 0;
+                    sort_exchange(k[e], v[e], s[e], j, lower == asc);
+                }
+            } else {
+                const int je = j >> 6;
+#pragma unroll
+                for (int e = 0; e < SE; e++) {
+#pragma unroll
+                    for (int f = 0; f < SE; f++) {
+                        // pairs (e, f = e ^ je) with e < f, both below ne
+                        if (f <= e || (e ^ f) != je || f >= ne) continue;
+                        const int i = 64 * e + LANE;
+                        const bool asc = (i & kk) == 0;
+                        const bool gt = k[e] > k[f] || (k[e] == k[f] && v[e] > v[f]);
+                        if (gt == asc) {
+                            const double tk = k[e]; k[e] = k[f]; k[f] = tk;
+                            const unsigned tv = v[e]; v[e] = v[f]; v[f] = tv;
+                            const unsigned tsv = s[e]; s[e] = s[f]; s[f] = tsv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- build: the sorted superset of everything within R, in LDS ----------------------------------------------------------
+// Returns the number of entries (>= 0), -1 if the sphere does not fit the slab.  q[e] receives the minimum-image r^2 of the
+// lane's entries (for the spheres of the radius rounds); g_W.shift / *fof0 the velocity and the FOF id of the innermost
+// particle (SO_properties.py:407-409).
+__device__ __forceinline__ int small_build(const CAS RunParams &P, double R, long long hindex, double (&q)[SE], long long *fof0) {
+#ifndef NO_SEL
+    const int n = small_select(P, R);
+#else
+    const int n = 77;
+#endif
+    if (n < 0) return -1;
+    WSYNC();
+    const double cx = g_W.c[0], cy = g_W.c[1], cz = g_W.c[2], L = g_W.L;
+    // the five payload pointers of the staged types (uniform: scalar registers)
+    const GAS Pay *pay0 = (const GAS Pay *)P.t[0].pay, *pay1 = (const GAS Pay *)P.t[1].pay, *pay2 = (const GAS Pay *)P.t[2].pay,
+                  *pay3 = (const GAS Pay *)P.t[3].pay;
+    double key[SE];
+    unsigned pv[SE], sl[SE];
+    // ---- gather in selection order: entry 64 e + lane
+    {
+        Pay rec[SE];
+        int ts[SE];
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            const int i = 64 * e + LANE;
+            pv[e] = 0xffffffffu; ts[e] = 1;
+            if (i < n) {
+                pv[e] = g_W.pidx[i];
+                ts[e] = (int)(pv[e] >> PIDX_BITS);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            const int i = 64 * e + LANE;
+            if (i < n) {
+                const unsigned p = pv[e] & PIDX_MASK;
+#if SHYDRO
+                const GAS Pay *base = ts[e] == 0 ? pay0 : (ts[e] == 1 ? pay1 : (ts[e] == 2 ? pay2 : pay3));
+#else
+                const GAS Pay *base = pay1;
+                (void)pay0; (void)pay2; (void)pay3;
+#endif
+                if (SCHECK((long long)p < P.t[1].n, 3, p)) rec[e] = load_pay(base + p);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            const int i = 64 * e + LANE;
+            key[e] = INFINITY; sl[e] = (unsigned)i; q[e] = INFINITY;
+            if (i < n) {
+                const Pay &R_ = rec[e];
+                const double wx = wrap_rel(R_.x, cx, L), wy = wrap_rel(R_.y, cy, L), wz = wrap_rel(R_.z, cz, L);
+                key[e] = sqrt((wx * wx + wy * wy) + wz * wz);
+                const double ax = min_image(R_.x, cx, L), ay = min_image(R_.y, cy, L), az = min_image(R_.z, cz, L);
+                g_W.dx[i] = wx; g_W.dy[i] = wy; g_W.dz[i] = wz;
+                g_W.vx[i] = R_.vx; g_W.vy[i] = R_.vy; g_W.vz[i] = R_.vz;
+                g_W.m[i] = R_.m;
+                g_W.r[i] = (ax * ax + ay * ay) + az * az;          // parked: the r column receives the sorted radii below
+                g_W.cum[i] = __longlong_as_double(R_.fof);         // parked: the cumulative mass is computed below
+                unsigned char fl = (unsigned char)ts[e];
+                if (R_.grnr == hindex) fl |= FL_BOUND;
+                if (R_.grnr >= 0 && R_.grnr != hindex) fl |= FL_SAT;   // "bound to another subhalo": satellite or external once the FOF id of the centre is known
+                g_W.flags[i] = fl;
+            }
+        }
+    }
+    // ---- sort by (r, packed index)
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+#ifndef NO_SORT
+    small_sort(key, pv, sl, lg);
+#endif
+    WSYNC();
+    // ---- the columns into sorted order: entry i takes what selection slot sl[e] holds (read everything, then write)
+#define PERMUTE_COL(col, T) { T t_[SE]; \
+        _Pragma("unroll") for (int e = 0; e < SE; e++) { t_[e] = (T)0; if (64 * e + LANE < n) t_[e] = g_W.col[sl[e]]; } \
+        WSYNC(); \
+        _Pragma("unroll") for (int e = 0; e < SE; e++) if (64 * e + LANE < n) g_W.col[64 * e + LANE] = t_[e]; \
+        WSYNC(); }
+#ifndef NO_PERM
+    PERMUTE_COL(dx, double) PERMUTE_COL(dy, double) PERMUTE_COL(dz, double)
+    PERMUTE_COL(vx, double) PERMUTE_COL(vy, double) PERMUTE_COL(vz, double)
+    PERMUTE_COL(m, double)
+    PERMUTE_COL(flags, unsigned char)
+#endif
+    long long fof[SE];
+#pragma unroll
+    for (int e = 0; e < SE; e++) { q[e] = INFINITY; fof[e] = 0; if (64 * e + LANE < n) { q[e] = g_W.r[sl[e]]; fof[e] = __double_as_longlong(g_W.cum[sl[e]]); } }
+    WSYNC();
+#pragma unroll
+    for (int e = 0; e < SE; e++) if (64 * e + LANE < n) { g_W.r[64 * e + LANE] = key[e]; g_W.pidx[64 * e + LANE] = pv[e]; }
+#undef PERMUTE_COL
+    // ---- the innermost particle: FOF id, velocity shift (no neutrinos in this class: it is entry 0)
+    const long long f0u = uni(fof[0]);
+    const long long f0 = n > 0 ? f0u : -1ll;
+    *fof0 = f0;
+    WSYNC();
+    double sh0 = 0.0, sh1 = 0.0, sh2 = 0.0;
+    if (n > 0) { sh0 = g_W.vx[0]; sh1 = g_W.vy[0]; sh2 = g_W.vz[0]; }
+    WSYNC();
+    if (LANE == 0) { g_W.shift[0] = sh0; g_W.shift[1] = sh1; g_W.shift[2] = sh2; }
+#pragma unroll
+    for (int e = 0; e < SE; e++) {
+        const int i = 64 * e + LANE;
+        if (i < n) {
+            g_W.vx[i] -= sh0; g_W.vy[i] -= sh1; g_W.vz[i] -= sh2;
+            unsigned char fl = g_W.flags[i];
+            if (fl & FL_SAT) { if (fof[e] != f0) fl = (unsigned char)((fl & ~FL_SAT) | FL_EXT); g_W.flags[i] = fl; }
+        }
+    }
+    WSYNC();
+    // ---- cumulative mass in numpy.cumsum order: ONE sequential chain (bit-identical to the reference, so that the SO
+    // radii and with them the SO memberships are); 16 LDS reads are in flight ahead of the chain
+#ifndef NO_CUM
+    if (LANE == 0) {
+        double run = 0.0;
+        int j = 0;
+        for (; j + 16 <= n; j += 16) {
+            double a_[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) a_[u] = g_W.m[j + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { run += a_[u]; a_[u] = run; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) g_W.cum[j + u] = a_[u];
+        }
+        for (; j < n; j++) { run += g_W.m[j]; g_W.cum[j] = run; }
+    }
+#endif
+    WSYNC();
+    return n;
+}
+
+// order the calculations of one family by prefix length (lanes = calculations): returns how many there are, *rank this
+// lane's position (or -1); g_W.bnd[k] the k-th prefix length
+__device__ __forceinline__ int small_family_order(bool in, int nc, int *rank_out) {
+    const unsigned long long members = __ballot(in);
+    const int m = __popcll(members);
+    int rank = 0;
+    unsigned long long rest = members;
+    while (rest) {
+        const int c2 = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const int n2 = rl(nc, c2);
+        if (n2 < nc || (n2 == nc && c2 < LANE)) rank++;
+    }
+    if (in) g_W.bnd[rank] = nc;
+    *rank_out = in ? rank : -1;
+    WSYNC();
+    return m;
+}
+
+// per-lane (= per-calculation) state of the radius loop and of stage B
+struct CalcState {
+    int state;        // 0 pending, 1 selection known, 2 done with zero columns, 3 copy of calculation n's columns
+    int n;            // prefix length of the selection (or the parent for copies)
+    int ev;           // >= 0: evaluated successfully in an earlier round (state to commit); after the commit: size of that round's sphere
+    double R, M;      // SO radius and mass
+};
+
+// ======================= stage B =========================================================================================
+// prefix moments of one family of calculations (bound_family: bound subhalo + exclusive spheres, else SO + inclusive
+// spheres): ONE pass over the slab, every block of 64 entries turned into inclusive wave scans, the lane that holds the last
+// member of a selection stores that selection's prefix moments (fused_moments_small of halo_kernel.inc).  Returns the
+// family's A_NFAR total through *nfar (bound family: np.isclose(r, 0) test of the unsoftened v_max).
+struct MomOut {       // what the later passes need of a calculation's prefix moments (this lane's calculation)
+    double M[4];      // mass per type slot
+    double N1;        // dark matter particles
+    double MV[3];     // sum m v' (slab frame)
+};
+__device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_family, const soap_calc_desc &cd, int coloff, const CalcState &cs,
+                                              bool in, int rank, int m, double soft1, double *nfar, MomOut *mo) {
+    *nfar = 0.0;
+    for (int t = 0; t < 4; t++) mo->M[t] = 0.0;
+    mo->N1 = 0.0; mo->MV[0] = mo->MV[1] = mo->MV[2] = 0.0;
+    if (m == 0) return;
+    const int nmax = rl(LANE < m ? g_W.bnd[LANE < m ? LANE : 0] : 0, m - 1);
+    const int my_nc = (LANE < m) ? g_W.bnd[LANE] : -1;
+#pragma unroll 1
+    for (int k0 = 0; k0 < m; k0 += SPREFB) {
+        const int k1 = (k0 + SPREFB < m) ? k0 + SPREFB : m;
+        for (int e = LANE; e < (k1 - k0) * SMOM; e += 64) (&g_W.prefc[0][0])[e] = 0.0;
+        WSYNC();
+#if !SHYDRO
+        // dark matter only: the per-type columns of the absent types stay zero and the dark matter sums ARE the all-particle
+        // sums -- 23 scans instead of 38, in two sweeps over the slab (12 + 11 running sums in registers instead of 23)
+        {
+            constexpr int NL = 12;
+            double carry[NL];
+#pragma unroll
+            for (int a = 0; a < NL; a++) carry[a] = 0.0;
+#pragma unroll 1
+            for (int base = 0; base < nmax; base += 64) {
+                const int i = base + LANE;
+                double c[NL];
+#pragma unroll
+                for (int a = 0; a < NL; a++) c[a] = 0.0;
+                if (i < nmax) {
+                    const unsigned char fl = g_W.flags[i];
+                    if (!bound_family || (fl & FL_BOUND)) {
+                        const double mm = g_W.m[i], r = g_W.r[i];
+                        const double x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i];
+                        const double u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+                        c[0] = 1.0; c[1] = mm;
+                        c[2] = mm * x; c[3] = mm * y; c[4] = mm * z;
+                        c[5] = mm * u; c[6] = mm * v; c[7] = mm * w;
+                        c[8] = mm * (y * w - z * v); c[9] = mm * (z * u - x * w); c[10] = mm * (x * v - y * u);
+                        c[11] = mm * r;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NL; a++) { c[a] = wave_scan(c[a], LANE) + carry[a]; if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+                for (int k = k0; k < k1; k++) {
+                    const int nc = rl(my_nc, k);
+                    if (nc > base && nc <= base + 64 && LANE == nc - 1 - base) {
+                        double *dst = g_W.prefc[k - k0];
+                        dst[A_N1] = c[0]; dst[A_M1] = c[1];
+                        dst[A_MX] = c[2]; dst[A_MX + 1] = c[3]; dst[A_MX + 2] = c[4];
+                        dst[A_MV] = c[5]; dst[A_MV + 1] = c[6]; dst[A_MV + 2] = c[7];
+                        dst[A_MVD] = c[5]; dst[A_MVD + 1] = c[6]; dst[A_MVD + 2] = c[7];
+                        dst[A_MXD] = c[2]; dst[A_MXD + 1] = c[3]; dst[A_MXD + 2] = c[4];
+                        dst[A_LA] = c[8]; dst[A_LA + 1] = c[9]; dst[A_LA + 2] = c[10];
+                        dst[A_LD] = c[8]; dst[A_LD + 1] = c[9]; dst[A_LD + 2] = c[10];
+                        dst[A_MR] = c[11];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NL; a++) carry[a] = rl64(c[a], 63);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            constexpr int NL = 11;
+            double carry[NL];
+#pragma unroll
+            for (int a = 0; a < NL; a++) carry[a] = 0.0;
+#pragma unroll 1
+            for (int base = 0; base < nmax; base += 64) {
+                const int i = base + LANE;
+                double c[NL];
+#pragma unroll
+                for (int a = 0; a < NL; a++) c[a] = 0.0;
+                if (i < nmax) {
+                    const unsigned char fl = g_W.flags[i];
+                    if (!bound_family || (fl & FL_BOUND)) {
+                        const double mm = g_W.m[i], r = g_W.r[i];
+                        const double u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+                        c[0] = mm * u * u; c[1] = mm * v * v; c[2] = mm * w * w;
+                        c[3] = mm * u * v; c[4] = mm * u * w; c[5] = mm * v * w;
+                        c[6] = mm * fmax(soft1, r);
+                        c[7] = (fl & FL_SAT) ? mm : 0.0;
+                        c[8] = (fl & FL_EXT) ? mm : 0.0;
+                        c[9] = (r > 1e-8) ? 1.0 : 0.0;
+                        c[10] = r;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NL - 1; a++) { c[a] = wave_scan(c[a], LANE) + carry[a]; if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+                c[10] = fmax(wave_scan_max(c[10]), carry[10]);
+                for (int k = k0; k < k1; k++) {
+                    const int nc = rl(my_nc, k);
+                    if (nc > base && nc <= base + 64 && LANE == nc - 1 - base) {
+                        double *dst = g_W.prefc[k - k0];
+                        dst[A_VV] = c[0]; dst[A_VV + 1] = c[1]; dst[A_VV + 2] = c[2]; dst[A_VV + 3] = c[3]; dst[A_VV + 4] = c[4]; dst[A_VV + 5] = c[5];
+                        dst[A_MRS] = c[6]; dst[A_MSAT] = c[7]; dst[A_MEXT] = c[8]; dst[A_NFAR] = c[9]; dst[A_RMAX] = c[10];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NL; a++) carry[a] = rl64(c[a], 63);
+            }
+            *nfar = carry[9];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#else
+#error "SHYDRO variant: not built yet"
+#endif
+        WSYNC();
+        if (in && rank >= k0 && rank < k1) {
+            const volatile double *a = g_W.prefc[rank - k0];
+#ifndef NO_FIN
+            finalize_moments(LANE, cd, rowbase + coloff, a, cs.R, cs.M);
+#endif
+#if SHYDRO
+            for (int t = 0; t < 4; t++) mo->M[t] = a[A_M0 + t];
+#else
+            mo->M[1] = a[A_M1];
+#endif
+            mo->N1 = a[A_N1];
+            for (int d = 0; d < 3; d++) mo->MV[d] = a[A_MV + d];
+        }
+        WSYNC();
+    }
+}
+
+// radial scan of one family (fused_scan of halo_kernel.inc on a single wave): v_max (kinematic_properties.py:555-593: arg-max
+// of M(<r) / max(r, softening), first maximum) at the end of every selection, the unsoftened v_max of the bound subhalo
+// (subhalo_properties.py:994-996), half-mass radii (half_mass_radius.py:40-80) -- then finalize_scan with lanes = calculations
+__device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_family, const soap_calc_desc &cd, int coloff, const CalcState &cs,
+                                           bool in, int m, const MomOut &mo, double soft1, double nfar_total, double nbound_total,
+                                           double *vs_out, double *rs_out) {
+    *vs_out = -1.0; *rs_out = 0.0;
+    if (m == 0) return;
+    const int nmax = rl(LANE < m ? g_W.bnd[LANE < m ? LANE : 0] : 0, m - 1);
+    // half-mass targets of this lane's calculation: [0] all members (bound subhalo only), [1] dark matter
+    double tg[SNHM];
+#pragma unroll
+    for (int w = 0; w < SNHM; w++) tg[w] = 0.0;
+    if (in) {
+        const double Mtot = ((mo.M[0] + mo.M[1]) + mo.M[2]) + mo.M[3];
+        if (cd.kind == SOAP_CALC_SUBHALO) { tg[0] = 0.5 * Mtot; tg[1] = 0.5 * mo.M[1]; }
+        else if (cd.kind == SOAP_CALC_APERTURE_INCL || cd.kind == SOAP_CALC_APERTURE_EXCL) tg[1] = 0.5 * mo.M[1];
+    }
+    double hm[SNHM];
+#pragma unroll
+    for (int w = 0; w < SNHM; w++) hm[w] = 0.0;
+    const bool want_unsoft = bound_family;
+    const bool allclose = bound_family && nbound_total > 0.0 && nfar_total == 0.0;
+    double carryA = 0.0, carryB = 0.0, carryC = 0.0, carryV = -1.0, carryS = 0.0;
+    double bestU = -1.0, bestUr = 0.0;
+    long long bestUi = 0x7fffffffffffffffLL;
+    double my_vs = -1.0, my_rs = 0.0;
+    const int my_n = in ? cs.n : -1;
+#pragma unroll 1
+    for (int base = 0; base < nmax; base += 64) {
+        const int i = base + LANE;
+        bool mem = false;
+        int t = 1;
+        double mm = 0.0, r = 0.0;
+        if (i < nmax) {
+            const unsigned char fl = g_W.flags[i];
+            mem = !bound_family || (fl & FL_BOUND);
+            t = fl & FL_TYPE;
+            if (mem) { mm = g_W.m[i]; r = g_W.r[i]; }
+        }
+        const double sA = wave_scan(mm, LANE) + carryA;
+#if SHYDRO
+        const double sB = wave_scan((t == 1) ? mm : 0.0, LANE) + carryB;
+#else
+        const double sB = sA;
+#endif
+        const double sC = wave_scan(mem ? 1.0 : 0.0, LANE) + carryC;
+        // ---- v_max: this particle's candidate, the running arg-max up to it (ties keep the lower index)
+        double wv = -1.0, ws = 0.0;
+        if (mem) {
+            const double sr = fmax(soft1, r);   // (SHYDRO: the softening of the particle's type)
+            if (sr > 1e-8) { wv = sA / sr; ws = sr; }
+            if (want_unsoft) {
+                const double rank = sC - 1.0;   // members before this one; nskip = 1 (subhalo_properties.py:994-996)
+                if (rank >= 1.0 && (r > 1e-8 || allclose) && r != 0.0) {
+                    const double val = sA / r;
+                    if (val > bestU) { bestU = val; bestUr = r; bestUi = i; }
+                }
+            }
+        }
+        wave_scan_argmax(wv, ws);
+        if (!(wv > carryV)) { wv = carryV; ws = carryS; }
+        // ---- the running maximum at the end of the selections that end in this block: fetched by the calculation's lane
+        {
+            const int j = my_n - 1 - base;
+            const int src = (j >= 0 && j < 64) ? j : 0;
+            const double bv = __shfl(wv, src, 64), bs = __shfl(ws, src, 64);
+            if (j >= 0 && j < 64) { my_vs = bv; my_rs = bs; }
+        }
+        // ---- half-mass crossings
+        const double pA = LANE == 0 ? carryA : dpp_f64<DPP_WAVE_SHR1>(sA), pB = LANE == 0 ? carryB : dpp_f64<DPP_WAVE_SHR1>(sB);
+#pragma unroll
+        for (int w = 0; w < SNHM; w++) {
+            unsigned long long open = __ballot(in && tg[w] > 0.0 && my_n > base);
+            while (open) {
+                const int c2 = __ffsll((long long)open) - 1;
+                open &= open - 1;
+                const double tgt = rl64(tg[w], c2);
+                const int n2 = rl(my_n, c2);
+                const double cv = w == 0 ? sA : sB;
+                const bool cls = w == 0 || t == 1;
+                const unsigned long long hit = __ballot(mem && cls && i < n2 && cv >= tgt);
+                if (!hit) continue;
+                const int owner = __ffsll((long long)hit) - 1;
+                // this particle is the first whose cumulative weight reaches the target (half_mass_radius.py:40-80); what is
+                // known about it is made uniform and every lane computes the same radius (no value that exists in one lane only)
+                const double cv_o = rl64(cv, owner), r_o = rl64(r, owner);
+                double Wmin = rl64(w == 0 ? pA : pB, owner), rmin = 0.0;
+                int j = base + owner - 1;   // previous member of the same class
+                while (j >= 0) {
+                    const unsigned char fj = g_W.flags[j];
+                    if ((!bound_family || (fj & FL_BOUND)) && (w == 0 || (fj & FL_TYPE) == 1)) break;
+                    j--;
+                }
+                if (j < 0) Wmin = 0.0; else rmin = g_W.r[j];
+                const double h = (Wmin == cv_o) ? 0.5 * (rmin + r_o) : rmin + (tgt - Wmin) / (cv_o - Wmin) * (r_o - rmin);
+                if (LANE == c2) { hm[w] = h; tg[w] = 0.0; }   // found: the target is closed
+            }
+        }
+        carryA = rl64(sA, 63); carryB = rl64(sB, 63); carryC = rl64(sC, 63);
+        carryV = rl64(wv, 63); carryS = rl64(ws, 63);
+    }
+    double vu = -1.0, ru = 0.0;
+    if (want_unsoft) {
+        // arg-max over all bound members, first maximum: largest value, then the smallest index
+        const double vmax = wave_max(bestU);
+        const long long icand = (bestU == vmax) ? bestUi : 0x7fffffffffffffffLL;
+        const long long imin = wave_min_ll(icand);
+        const unsigned long long who = __ballot(bestU == vmax && bestUi == imin);
+        const int src = __ffsll((long long)who) - 1;
+        vu = vmax; ru = rl64(bestUr, src < 0 ? 0 : src);
+    }
+    if (in) {
+        ScanResult sr;
+        sr.vs = my_vs; sr.rs = my_rs; sr.vu = vu; sr.ru = ru;
+#pragma unroll
+        for (int w = 0; w < NHM; w++) sr.hm[w] = w < SNHM ? hm[w < SNHM ? w : 0] : 0.0;
+        sr.cs_R = cs.R;
+        finalize_scan(cd, rowbase + coloff, sr);
+    }
+    *vs_out = my_vs; *rs_out = my_rs;
+}
+
+// BoundSubhalo spin: bound particles with r <= R_vmax_soft about the subhalo's vcom (subhalo_properties.py:1046-1073);
+// vs / rs: the soft v_max result of calculation 0, Mtot / mv: its total mass and sum m v'
+__device__ __forceinline__ void small_subhalo_spin(GAS double *row, int n0, double vs, double rs, double Mtot, const double *mv) {
+    const double vmax_s = (Mtot != 0.0 && vs > 0.0) ? sqrt(vs * g_S.G_eff) : 0.0;
+    const double rmax_s = (Mtot != 0.0 && vs > 0.0) ? rs : 0.0;
+    if (!(Mtot != 0.0 && rmax_s > 0.0 && vmax_s > 0.0)) return;
+    double sm = 0.0, mx0 = 0.0, mx1 = 0.0, mx2 = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < SE; e++) {
+        const int i = 64 * e + LANE;
+        if (i < n0 && (g_W.flags[i] & FL_BOUND) && g_W.r[i] <= rmax_s) {
+            const double mm = g_W.m[i], x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i], u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+            sm += mm; mx0 += mm * x; mx1 += mm * y; mx2 += mm * z;
+            l0 += mm * (y * w - z * v); l1 += mm * (z * u - x * w); l2 += mm * (x * v - y * u);
+        }
+    }
+    const double p1 = wave_sum4(sm, mx0, mx1, mx2), p2 = wave_sum4(l0, l1, l2, 0.0);
+    double b[NACC];
+    for (int k = 0; k < NACC; k++) b[k] = 0.0;
+    const double Mr = rl64(p1, 0);
+    b[A_MX] = rl64(p1, 16); b[A_MX + 1] = rl64(p1, 32); b[A_MX + 2] = rl64(p1, 48);
+    b[A_LA] = rl64(p2, 0); b[A_LA + 1] = rl64(p2, 16); b[A_LA + 2] = rl64(p2, 32);
+    if (LANE == 0 && Mr > 0.0) {
+        double dv[3];
+        // row[SH_vcom] - shift, as the general path reads it back
+        const double iMt = 1.0 / Mtot;
+        for (int d = 0; d < 3; d++) dv[d] = (mv[d] * iMt + g_S.shift[d]) - g_S.shift[d];
+        row[SH_spin] = norm_L_about(b, dv) / (sqrt(2.0) * Mr * vmax_s * rmax_s);
+    }
+}
+
+// ======================= dark matter mass flow rates (SO_properties.py:2791-2932; flow_batch of halo_kernel.inc) =========
+// Mass flux of the dark matter through shells of width dR = 0.1 R centred on R = 0.1, 0.3, 1 R_SO: radial velocity relative
+// to the centre-of-mass velocity of ALL particles inside R and to the pseudo-evolution of the radius; sum of m |v_r| / dR
+// over the inflowing and the outflowing particles.  One calculation per call: SO_r / SO_mass its radius and mass, vc_own the
+// centre-of-mass velocity of its sphere in the frame of the slab velocities, n the size of the search sphere.
+__device__ __forceinline__ void small_flow_one(const CAS RunParams &P, GAS double *crow, double SO_r, double SO_mass, const double *vc_own, int n) {
+    // ---- bounds: lane b < 8 (two inner spheres, three shells)
+    int bnd = 0;
+    {
+        const int b = LANE & 7;
+        double T;
+        bool strict = true;
+        if (b < 2) T = (b == 0 ? 0.1 : 0.3) * SO_r;        // radius < R_frac * SO_r (:2796, :2808)
+        else {
+            const int sh = (b - 2) >> 1;
+            const double R = (sh == 0 ? 0.1 : sh == 1 ? 0.3 : 1.0) * SO_r, dR = 0.1 * R;
+            if ((b & 1) == 0) { T = R - (dR / 2); strict = false; }   // first index with r > lo
+            else T = R + (dR / 2);                                    // first index with r >= hi
+        }
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const double rv = g_W.r[mid];
+            if (strict ? (rv < T) : (rv <= T)) lo = mid + 1; else hi = mid;
+        }
+        bnd = lo;
+    }
+    const int k10 = rl(bnd, 0), k30 = rl(bnd, 1);
+    // ---- pass 1: sum m, sum m v' and the particle count inside 0.1 and 0.3 R_SO (prefixes of the sorted slab)
+    double vc[3][3];
+    {
+        double a[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) a[k] = 0.0;
+        for (int i = LANE; i < k30; i += 64) {
+            const double mm = g_W.m[i], ux = g_W.vx[i], uy = g_W.vy[i], uz = g_W.vz[i];
+            const double mx = mm * ux, my = mm * uy, mz = mm * uz;
+            const bool in10 = i < k10;
+            a[0] += in10 ? mm : 0.0; a[1] += in10 ? mx : 0.0; a[2] += in10 ? my : 0.0; a[3] += in10 ? mz : 0.0;
+            a[4] += mm; a[5] += mx; a[6] += my; a[7] += mz;
+            a[8] += in10 ? 1.0 : 0.0; a[9] += 1.0;
+        }
+        const double p1 = wave_sum4(a[0], a[1], a[2], a[3]), p2 = wave_sum4(a[4], a[5], a[6], a[7]), p3 = wave_sum4(a[8], a[9], 0.0, 0.0);
+        const double cnt10 = rl64(p3, 0), cnt30 = rl64(p3, 16);
+        const double m10 = rl64(p1, 0), m30 = rl64(p2, 0);
+        const double s10x = rl64(p1, 16), s10y = rl64(p1, 32), s10z = rl64(p1, 48), s30x = rl64(p2, 16), s30y = rl64(p2, 32), s30z = rl64(p2, 48);
+        // no particle inside: zero velocity ("HaloCentre doesn't actually need to be on top of a particle", :2860-2863)
+        vc[0][0] = cnt10 == 0.0 ? -g_S.shift[0] : s10x / m10;
+        vc[0][1] = cnt10 == 0.0 ? -g_S.shift[1] : s10y / m10;
+        vc[0][2] = cnt10 == 0.0 ? -g_S.shift[2] : s10z / m10;
+        vc[1][0] = cnt30 == 0.0 ? -g_S.shift[0] : s30x / m30;
+        vc[1][1] = cnt30 == 0.0 ? -g_S.shift[1] : s30y / m30;
+        vc[1][2] = cnt30 == 0.0 ? -g_S.shift[2] : s30z / m30;
+        vc[2][0] = vc_own[0]; vc[2][1] = vc_own[1]; vc[2][2] = vc_own[2];
+    }
+    // ---- pass 2: the shells, their index ranges laid end to end
+    int base[3], off[4];
+    off[0] = 0;
+#pragma unroll
+    for (int sh = 0; sh < 3; sh++) {
+        const int i0 = rl(bnd, 2 + 2 * sh), i1 = rl(bnd, 3 + 2 * sh);
+        off[sh + 1] = off[sh] + (i1 > i0 ? i1 - i0 : 0);
+        base[sh] = i0 - off[sh];
+    }
+    // R_dot = (2/3) (G M H / 100)^(1/3) (2 Omega_g + 3/2 Omega_m) R_frac   (:2875-2884)
+    double Rd0 = (2.0 / 3.0) * cbrt(P.G_phys * SO_mass * P.hubble / 100.0);
+    Rd0 *= P.rdot_omega;
+    double fin[3] = {0.0, 0.0, 0.0}, fout[3] = {0.0, 0.0, 0.0};
+    const int total = off[3];
+    for (int j = LANE; j < total; j += 64) {
+        const int sh = (j >= off[1] ? 1 : 0) + (j >= off[2] ? 1 : 0);
+        const int i = j + (sh == 0 ? base[0] : (sh == 1 ? base[1] : base[2]));
+        const unsigned char tf = g_W.flags[i];
+        const double rr = g_W.r[i], mm = g_W.m[i];
+        const double x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i];
+        const double ux = g_W.vx[i], uy = g_W.vy[i], uz = g_W.vz[i];
+        const double vc0 = sh == 0 ? vc[0][0] : (sh == 1 ? vc[1][0] : vc[2][0]);
+        const double vc1 = sh == 0 ? vc[0][1] : (sh == 1 ? vc[1][1] : vc[2][1]);
+        const double vc2 = sh == 0 ? vc[0][2] : (sh == 1 ? vc[1][2] : vc[2][2]);
+        const double R_dot = Rd0 * (sh == 0 ? 0.1 : sh == 1 ? 0.3 : 1.0);
+        const bool dmp = (tf & FL_TYPE) == 1;   // dark matter only
+        const double ir = 1.0 / rr;
+        double v_r = ((ux - vc0) * (x * ir) + (uy - vc1) * (y * ir)) + (uz - vc2) * (z * ir);
+        v_r -= R_dot;
+        const double fl = mm * fabs(v_r);
+        const bool in = dmp && v_r < 0.0, out = dmp && v_r > 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            fin[k] += (in && sh == k) ? fl : 0.0;
+            fout[k] += (out && sh == k) ? fl : 0.0;
+        }
+    }
+    const double q1 = wave_sum4(fin[0], fin[1], fin[2], fout[0]), q2 = wave_sum4(fout[1], fout[2], 0.0, 0.0);
+    // lane k < 6: inflow at 0.1 / 0.3 / 1 R_SO, outflow at the same (the six totals are read across the lanes BEFORE the
+    // lane-dependent choice: a cross-lane read inside a lane-dependent branch sees only that branch's lanes)
+    const double t0 = rl64(q1, 0), t1 = rl64(q1, 16), t2 = rl64(q1, 32), t3 = rl64(q1, 48), t4 = rl64(q2, 0), t5 = rl64(q2, 16);
+    const double v = LANE == 0 ? t0 : LANE == 1 ? t1 : LANE == 2 ? t2 : LANE == 3 ? t3 : LANE == 4 ? t4 : t5;
+    if (LANE < 6) {
+        const double R = (LANE % 3 == 0 ? 0.1 : LANE % 3 == 1 ? 0.3 : 1.0) * SO_r;
+        crow[SOC_flow + LANE] = v / (0.1 * R);
+    }
+}
+
+// ======================= the kernel =======================================================================================
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWPE, 8)))
+k_small(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo) {
+    const CAS RunParams &P = *(const CAS RunParams *)Pp;
+    const int ncalc = P.ncalc;
+    const long long ncols = P.ncols;
+    // ---- this lane's calculation: kind, flags and virial definition stay in a register, the rest of the descriptor is
+    // fetched again where the radius loop evaluates the calculation (a handful of cached loads per halo against ten
+    // registers held through every phase)
+    int kfv = -1, coloff = 0;
+    if (LANE < ncalc) {
+        const GAS soap_calc_desc *g = (const GAS soap_calc_desc *)P.calcs + LANE;
+        kfv = (g->kind & 0xff) | ((g->flags & 0xff) << 8) | ((g->virial_definition & 0xff) << 16);
+        coloff = ((const GAS int *)P.coloff)[LANE];
+    }
+    soap_calc_desc cd;   // kind / flags / virial definition of this lane's calculation (what stage B needs)
+    cd.kind = kfv < 0 ? -1 : (kfv & 0xff); cd.flags = kfv < 0 ? 0 : ((kfv >> 8) & 0xff); cd.virial_definition = kfv < 0 ? 0 : ((kfv >> 16) & 0xff);
+    cd.parent = -1; cd.reference_density = 0.0; cd.radius = 0.0; cd.physical_radius_mpc = 0.0; cd.prev_radius = 0.0; cd.filter_limit = 0; cd.filter_types = 0;
+    const double subhalo_required = ((const CAS soap_calc_desc *)P.calcs)[0].physical_radius_mpc;
+    const unsigned long long so_lanes = __ballot(LANE < ncalc && cd.kind == SOAP_CALC_SO_DENSITY);
+    const unsigned long long flow_lanes = __ballot(LANE < ncalc && cd.kind == SOAP_CALC_SO_DENSITY && (cd.flags & SOAP_CALC_FLAG_DM_FLOW));
+    if (LANE == 0) {
+        g_W.L = P.boxsize; g_W.nu_density = P.nu_density; g_W.a = P.a; g_W.mpc = P.mpc; g_W.mpc20 = P.mpc20; g_W.G_eff = P.G_eff;
+        g_W.hydro = P.hydro; g_W.has_nu = P.has_nu;
+#ifdef SMALL_CHECK
+        g_W.dbg = (unsigned long long *)P.phase;
+#endif
+    }
+    WSYNC();
+    const double soft1 = P.soft[1];
+    const int dbg_stop = P.profile >= 100 ? P.profile - 100 : 0;   // diagnostics: SOAP_ENGINE_PROFILE=100+k ends every halo after phase k
+    if (dbg_stop == 9) return;
+    const double target_density = P.target_density, first_factor = P.first_factor;
+    const GAS double *h_cofp = (const GAS double *)P.halo.cofp;
+    GAS double *h_search = (GAS double *)P.halo.search_radius, *h_read = (GAS double *)P.halo.read_radius;
+    const GAS long long *h_index = (const GAS long long *)P.halo.index, *h_nrbound = (const GAS long long *)P.halo.nr_bound;
+    const GAS int *h_central = (const GAS int *)P.halo.is_central;
+    const GAS double *h_resident = (const GAS double *)P.halo.resident;
+    GAS int *h_status = (GAS int *)P.halo.status;
+    GAS long long *h_stats = (GAS long long *)P.halo.stats;
+    GAS double *table = (GAS double *)P.table;
+    GAS unsigned *gqueue = (GAS unsigned *)queue;
+    const GAS int *gtodo = (const GAS int *)todo;
+    const unsigned long long alldone = (ncalc >= 64) ? ~0ull : ((1ull << ncalc) - 1ull);
+
+#pragma unroll 1
+    while (true) {
+        // (the ticket travels through LDS, as in halo_kernel.inc: a value defined in lane 0's branch and read back with
+        // readfirstlane was compiled into a loop exit that only lane 0 takes -- the other lanes spun on ticket 0)
+        WSYNC();
+        if (LANE == 0) g_W.ticket = atomicAdd((unsigned *)gqueue, 1u);
+        WSYNC();
+        const long long task = (long long)(unsigned)uni((int)g_W.ticket);
+        if (task >= n_todo) break;
+        const long long hrow = (long long)uni(gtodo[task]);
+        if (!SCHECK(hrow >= 0 && hrow < P.halo.n, 0, hrow)) continue;
+        const unsigned long long t_begin = __builtin_readcyclecounter();
+        const double c0 = uni(h_cofp[3 * hrow]), c1 = uni(h_cofp[3 * hrow + 1]), c2 = uni(h_cofp[3 * hrow + 2]);
+        const long long hindex = uni(h_index[hrow]);
+        double Rread = uni(h_read[hrow]);
+        double Rsearch = uni(h_search[hrow]);
+        const double Rresident = h_resident ? uni(h_resident[hrow]) : Rread;
+        const int central = uni(h_central[hrow]);
+        const long long nr_bound = uni(h_nrbound[hrow]);
+        WSYNC();
+        if (LANE == 0) { g_W.c[0] = c0; g_W.c[1] = c1; g_W.c[2] = c2; }
+        WSYNC();
+        const bool use_target = central == 1 && target_density > 0.0;
+        GAS double *row = table + hrow * ncols;
+        for (long long k = LANE; k < ncols; k += 64) row[k] = 0.0;   // columns nobody writes stay zero
+        if (dbg_stop == 8) { if (LANE == 0) h_status[hrow] = SOAP_HALO_OK; continue; }
+#ifdef SMALL_STUB8
+        { if (LANE == 0) h_status[hrow] = SOAP_HALO_OK; continue; }
+#endif
+        CalcState cs;
+        cs.state = 0; cs.n = 0; cs.ev = -1; cs.R = 0.0; cs.M = 0.0;
+        double counts[4] = {0.0, 0.0, 0.0, 0.0};
+        double encl = 0.0;
+        unsigned long long done = 0ull;
+        double Rcur = Rsearch;
+        int status = SOAP_HALO_OK;
+        long long n_loop = 0, n_loop_all = 0, ncand = 0;
+        int n_restart = 0, nsel_final = 0;
+        double R_have = -1.0;
+        int n_have = 0;
+        double q[SE];
+        long long fof0 = -1;
+#pragma unroll
+        for (int e = 0; e < SE; e++) q[e] = INFINITY;
+#pragma unroll 1
+        while (true) {
+            n_loop++; n_loop_all++;
+            if (!(Rcur <= Rread) || n_loop_all > 100000) { status = SOAP_HALO_FATAL_RADIUS_ASSERT; break; }   // (halo_tasks.py:78; the count: a radius that cannot grow, e.g. 0)
+            // the sorted superset has to cover Rcur: built a few radius steps ahead of the loop, built again further out
+            // when the loop outruns it (a rebuild from scratch: everything fits the registers and LDS of the wave)
+            if (Rcur > R_have) {
+                const double R_new = uni(fmin(Rread, fmax(Rcur, (R_have < 0.0 ? Rsearch * first_factor : R_have * 1.728))));
+#ifndef NO_BUILD
+                const int nb_ = small_build(P, R_new, hindex, q, &fof0);
+#else
+                const int nb_ = 5;
+#endif
+                if (nb_ < 0) { status = SOAP_HALO_FATAL_SLAB_OVERFLOW; break; }
+                n_have = nb_;
+                R_have = R_new;
+                if (dbg_stop == 1) break;
+            }
+            // the sphere of this round: entries with minimum-image r^2 <= Rcur^2 (shared_mesh.py:191-194); they have to be a
+            // prefix of the slab (they are, unless two particles straddle the radius within rounding: general path)
+            int n = n_have;
+            if (Rcur != R_have) {
+                const double R2 = uni(Rcur * Rcur);
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < SE; e++) cnt += __popcll(__ballot(64 * e + LANE < n_have && q[e] <= R2));
+                int chk = 0;
+#pragma unroll
+                for (int e = 0; e < SE; e++) chk += __popcll(__ballot(64 * e + LANE < cnt && q[e] <= R2));
+                if (chk != cnt) { status = SOAP_HALO_FATAL_SLAB_OVERFLOW; break; }
+                n = cnt;
+            }
+            nsel_final = n;
+            if (dbg_stop == 2) break;
+            double required = 0.0;
+            // density = mass_total / (4/3 pi R^3) <= target  (halo_tasks.py:97-103)
+            const double mass_total = n > 0 ? g_W.cum[n - 1] : 0.0;
+            const double density = uni(mass_total / (4.0 / 3.0 * M_PI * cube(Rcur)));
+            if (!use_target || density <= target_density) {
+                int fatal = 0;
+                bool stop = false;
+                if (!(done & 1ull)) {
+                    // BoundSubhalo gate (subhalo_properties.py:2618-2646): bound-particle counts per type + enclose radius
+                    int cb[4] = {0, 0, 0, 0};
+                    int last = -1;
+#pragma unroll
+                    for (int e = 0; e < SE; e++) {
+                        const int i = 64 * e + LANE;
+                        const unsigned char fl = i < n ? g_W.flags[i] : (unsigned char)0;
+                        const bool bd = (fl & FL_BOUND) != 0;
+                        const unsigned long long bm = __ballot(bd);
+                        if (bm) { const int hi = 64 * e + 63 - __clzll((long long)bm); last = hi > last ? hi : last; }
+#if SHYDRO
+#pragma unroll
+                        for (int tt = 0; tt < 4; tt++) cb[tt] += __popcll(__ballot(bd && (fl & FL_TYPE) == tt));
+#else
+                        cb[1] += __popcll(bm);
+#endif
+                    }
+                    const double tot[4] = {uni((double)cb[0]), uni((double)cb[1]), uni((double)cb[2]), uni((double)cb[3])};
+                    const double Ntot = ((tot[0] + tot[1]) + tot[2]) + tot[3];
+                    if (Ntot < (double)nr_bound) { required = uni(fmax(required, subhalo_required)); stop = true; }   // subhalo_properties.py:2634
+                    else if (Ntot > (double)nr_bound) fatal = SOAP_HALO_FATAL_TOO_MANY_BOUND;                                            // :2642
+                    else {
+                        for (int k = 0; k < 4; k++) counts[k] = tot[k];
+                        encl = uni(last >= 0 ? g_W.r[last] : 0.0);
+                        if (LANE == 0) { cs.state = 1; cs.n = n; cs.R = 0.0; cs.M = 0.0; }
+                        done |= 1ull;
+                    }
+                }
+                if (!stop && !fatal && done != alldone) {
+                    // nskip = max(1, argmax(r > 0))  (SO_properties.py:416): the radii are sorted, the zeros lead
+                    int nskip = 1;
+                    if (central && n > 0) {
+                        int nz = 0;
+#pragma unroll
+                        for (int e = 0; e < SE; e++) { const int i = 64 * e + LANE; nz += __popcll(__ballot(i < n && !(g_W.r[i < n ? i : 0] > 0.0))); }
+                        nskip = nz == n ? 0 : nz;
+                        nskip = nskip < 1 ? 1 : nskip;
+                    }
+                    // first entry >= 1 whose enclosed density is not above the threshold of each SO density calculation
+                    // (SO_properties.py:140-146), found with the lanes on the entries; kept by the calculation's lane
+                    soap_calc_desc cdf = cd;   // the full descriptor of this lane's calculation
+                    if (LANE < ncalc) {
+                        const GAS soap_calc_desc *g = (const GAS soap_calc_desc *)P.calcs + LANE;
+                        cdf.parent = g->parent; cdf.reference_density = g->reference_density; cdf.radius = g->radius;
+                        cdf.physical_radius_mpc = g->physical_radius_mpc; cdf.prev_radius = g->prev_radius;
+                        cdf.filter_limit = g->filter_limit; cdf.filter_types = g->filter_types;
+                    }
+                    int my_fb = -1;
+                    {
+                        unsigned long long pend = so_lanes & ~done;
+                        if (pend && central) {
+                            double de[SE];
+#pragma unroll
+                            for (int e = 0; e < SE; e++) { const int i = 64 * e + LANE; de[e] = (i >= 1 && i < n) ? small_dens(i) : INFINITY; }
+                            while (pend) {
+                                const int c2 = __ffsll((long long)pend) - 1;
+                                pend &= pend - 1;
+                                const double rho = rl64(cdf.reference_density, c2);
+                                int first = 0x7fffffff;
+#pragma unroll
+                                for (int e = SE - 1; e >= 0; e--) {
+                                    const unsigned long long bm = __ballot(!(de[e] > rho));
+                                    if (bm) first = 64 * e + __ffsll((long long)bm) - 1;
+                                }
+                                if (LANE == c2) my_fb = first;
+                            }
+                        }
+                    }
+                    {
+                        const int c = LANE;
+                        const bool pending = c > 0 && c < ncalc && !((done >> c) & 1ull);
+                        int res = RES_OK, st = 2, nin = 0;
+                        double Rv = 0.0, Mv = 0.0, creq = 0.0;
+                        bool filt = true;
+                        // A selection found in an earlier round stays what it is when the sphere grows (it is a prefix of the
+                        // sorted slab): such lanes only wait for the calculations before them.
+                        const bool cached = pending && cs.ev >= 0;
+                        if (cached) { st = cs.ev; nin = cs.n; Rv = cs.R; Mv = cs.M; creq = cdf.physical_radius_mpc; }
+                        if (pending && !cached) {
+                            creq = cdf.physical_radius_mpc;
+                            // category filter of the calculation (category_filter.py:69-106)
+                            if (cdf.filter_limit > 0) {
+                                double v = 0.0;
+                                for (int t = 0; t < 4; t++) if (cdf.filter_types & (1 << t)) v += counts[t];
+                                filt = v >= (double)cdf.filter_limit;
+                            }
+                            if (cdf.kind == SOAP_CALC_SO_DENSITY || cdf.kind == SOAP_CALC_SO_PHYSICAL) {
+                                #ifndef NO_SO
+                                if (central && filt) res = so_eval_lane(cdf, Rcur, n, nskip, 0.0, my_fb, &creq, &st, &nin, &Rv, &Mv);
+#endif
+                            } else if (cdf.kind == SOAP_CALC_APERTURE_INCL || cdf.kind == SOAP_CALC_APERTURE_EXCL) {
+                                bool skip = false;
+                                int copy_from = -1;
+                                const double Rap = cdf.radius;
+                                if (cdf.parent >= 0) {
+                                    // aperture_properties.py:4086-4123, EncloseRadius as stored (float32)
+                                    const float enc = (float)encl;
+                                    if (cdf.prev_radius > (double)enc) {
+                                        skip = true;
+                                        if (cdf.kind == SOAP_CALC_APERTURE_EXCL && filt) copy_from = cdf.parent;
+                                    }
+                                }
+                                if (filt && !skip) {
+                                    if (Rcur < Rap) res = RES_TOO_SMALL;   // aperture_properties.py:4140-4143
+                                    else { st = 1; nin = count_r_le(n, Rap); Rv = Rap; }   // r <= R_ap (:310)
+                                } else if (copy_from >= 0) { st = 3; nin = copy_from; }
+                            }
+                        }
+                        if (pending && !cached && res == RES_OK && (st == 1 || st == 3) && cdf.kind != SOAP_CALC_SO_MULTIPLE) {
+                            cs.ev = st; cs.n = nin; cs.R = Rv; cs.M = Mv;
+                        }
+                        // DarkMatterMassFlowRate: the shell around R_SO reaches R + dR/2 with dR = 0.1 R; beyond the search radius the
+                        // reference raises SearchRadiusTooSmallError (SO_properties.py:2846-2850), unless no dark matter lies
+                        // inside R_SO (:2923).  Checked every round, also for a cached selection.
+                        if (pending && res == RES_OK && st == 1 && cdf.kind == SOAP_CALC_SO_DENSITY && (cdf.flags & SOAP_CALC_FLAG_DM_FLOW)) {
+                            const double dR = 0.1 * Rv;
+                            if (Rv + (dR / 2) > Rcur) {
+                                bool has_dm = false;
+                                for (int i = 0; i < nin && !has_dm; i++) has_dm = (g_W.flags[i] & FL_TYPE) == 1;
+                                if (has_dm) res = RES_TOO_SMALL;
+                            }
+                        }
+                        // radius multiples need their parent: finished in an earlier round or evaluated just now (its lane)
+                        const bool is_mult = pending && cdf.kind == SOAP_CALC_SO_MULTIPLE;
+                        const int par = is_mult ? cdf.parent : 0;
+                        const int p_res = __shfl(res, par, 64), p_st = __shfl(st, par, 64);
+                        const double p_R = __shfl(Rv, par, 64);
+                        const int p_cstate = __shfl(cs.state, par, 64);
+                        const double p_cR = __shfl(cs.R, par, 64);
+                        if (is_mult && central && filt) {
+                            double rp;
+                            if ((done >> par) & 1ull) rp = (p_cstate == 1) ? p_cR : 0.0;
+                            else rp = (p_res == RES_OK && p_st == 1) ? p_R : 0.0;
+#ifndef NO_SO2
+                            res = so_eval_lane(cdf, Rcur, n, nskip, rp, -1, &creq, &st, &nin, &Rv, &Mv);
+#endif
+                        }
+                        const unsigned long long failm = __ballot(pending && res != RES_OK);
+                        const int f = failm ? __ffsll((long long)failm) - 1 : 64;
+                        const bool commit = pending && c < f;
+                        // (ev keeps the size of the search sphere of the round in which the calculation was committed)
+                        if (commit) { cs.state = st; cs.n = nin; cs.R = Rv; cs.M = Mv; cs.ev = n; }
+                        done |= __ballot(commit);
+                        const int fres = __shfl(res, f & 63, 64);
+                        const double freq = __shfl(creq, f & 63, 64);
+                        if (f < 64) {
+                            if (fres == RES_TOO_SMALL) required = uni(fmax(required, freq));
+                            else if (fres < 0) fatal = fres;
+                        }
+                    }
+                }
+                if (fatal) { status = fatal; break; }
+                #ifndef NO_CC
+                if (done == alldone) { ncand = small_count_candidates(P, Rcur); break; }
+#else
+                if (done == alldone) break;
+#endif
+            }
+            // halo_tasks.py:167-187
+            if (required > Rread || Rcur >= Rread) {
+                Rsearch = uni(fmax(Rsearch, required > Rread ? required : Rcur));
+                const double Rread_new = uni(fmax(Rread * 1.5, Rsearch));   // halo_tasks.py:393-402
+                if (Rread_new <= Rresident && n_restart < 64) {
+                    // the enlarged region is already resident: what the next process_halos call would do with the halo -- start
+                    // again from the new search radius with every calculation open (halo_tasks.py:23-74) -- happens here
+                    Rread = Rread_new;
+                    n_restart++;
+                    for (int k = 0; k < 4; k++) counts[k] = 0.0;
+                    cs.state = 0; cs.ev = -1;
+                    encl = 0.0;
+                    done = 0ull;
+                    Rcur = Rsearch;
+                    n_loop = 0;
+                    continue;
+                }
+                status = SOAP_HALO_NEED_LARGER_READ_RADIUS;
+                break;
+            } else {
+                Rcur = fmin(Rcur * 1.2, Rread);
+                Rcur = uni(fmax(Rcur, required));
+            }
+        }
+        if (status == SOAP_HALO_OK && dbg_stop != 1 && dbg_stop != 2 && dbg_stop != 3) {
+            // ---- stage B: every property of every calculation in a few fused passes over the sorted slab
+            if (LANE == 0 && cs.state == 1) cs.n = nsel_final;   // all bound particles lie inside any later sphere
+            const int kind = cd.kind;
+            const bool isb = kind == SOAP_CALC_SUBHALO || kind == SOAP_CALC_APERTURE_EXCL;
+            const bool fam = LANE < ncalc && cs.state == 1 && kind != SOAP_CALC_PROJECTED;
+            const double nbound_total = uni(((counts[0] + counts[1]) + counts[2]) + counts[3]);
+            int rank;
+            // ---- all particles: SO + inclusive spheres (moments, radial scan, flow rates), then the bound particles: subhalo +
+            // exclusive spheres (moments, radial scan, spin).  The two families write disjoint columns.
+            {
+                MomOut mo;
+                double nfar, vs, rs;
+                const int m = small_family_order(fam && !isb, cs.n, &rank);
+#ifndef NO_MOM
+                small_moments(row, false, cd, coloff, cs, fam && !isb, rank, m, soft1, &nfar, &mo);
+#endif
+#ifndef NO_SCAN
+                if (dbg_stop != 4)
+                small_scan(row, false, cd, coloff, cs, fam && !isb, m, mo, soft1, nfar, nbound_total, &vs, &rs);
+#endif
+#ifndef NO_FLOW
+                if (dbg_stop != 4 && dbg_stop != 5) {
+                // dark matter mass flow rates of the virial SO definitions that exist and hold dark matter (:2923)
+                unsigned long long fl = flow_lanes & __ballot(cs.state == 1 && mo.N1 != 0.0);
+                // the sphere's own centre-of-mass velocity in the frame of the slab velocities: row[SOC_vcom] - shift, as the
+                // general path reads it back
+                double vc_own[3];
+                {
+                    const double Mtot = ((mo.M[0] + mo.M[1]) + mo.M[2]) + mo.M[3];
+                    const double iMt = 1.0 / Mtot;
+                    for (int d = 0; d < 3; d++) vc_own[d] = Mtot != 0.0 ? (mo.MV[d] * iMt + g_S.shift[d]) - g_S.shift[d] : -g_S.shift[d];
+                }
+                while (fl) {
+                    const int c2 = __ffsll((long long)fl) - 1;
+                    fl &= fl - 1;
+                    const double vo[3] = {rl64(vc_own[0], c2), rl64(vc_own[1], c2), rl64(vc_own[2], c2)};
+                    small_flow_one(P, row + rl(coloff, c2), rl64(cs.R, c2), rl64(cs.M, c2), vo, nsel_final);
+                }
+                }
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (dbg_stop == 0 || dbg_stop > 6) {
+                MomOut mo;
+                double nfar, vs, rs;
+                const int m = small_family_order(fam && isb, cs.n, &rank);
+#ifndef NO_MOM
+                small_moments(row, true, cd, coloff, cs, fam && isb, rank, m, soft1, &nfar, &mo);
+#endif
+#ifndef NO_SCAN
+                small_scan(row, true, cd, coloff, cs, fam && isb, m, mo, soft1, nfar, nbound_total, &vs, &rs);
+                if (rl(cs.state, 0) == 1) {
+                    const double Mt0 = rl64(((mo.M[0] + mo.M[1]) + mo.M[2]) + mo.M[3], 0);
+                    const double mv0[3] = {rl64(mo.MV[0], 0), rl64(mo.MV[1], 0), rl64(mo.MV[2], 0)};
+                    small_subhalo_spin(row + rl(coloff, 0), rl(cs.n, 0), rl64(vs, 0), rl64(rs, 0), Mt0, mv0);
+                }
+#endif
+            }
+            // exclusive spheres that repeat the next-smaller one (aperture_properties.py:4117-4123): copies of its columns
+            {
+                unsigned long long cp = __ballot(LANE < ncalc && cs.state == 3);
+                if (cp) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the parents' columns were written by other lanes
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    while (cp) {
+                        const int c2 = __ffsll((long long)cp) - 1;
+                        cp &= cp - 1;
+                        const int par = rl(cs.n, c2);
+                        const GAS double *prow = row + rl(coloff, par);
+                        GAS double *crow = row + rl(coloff, c2);
+                        // (chains: a copy of a copy reads what the earlier iteration of this loop wrote)
+                        double v = 0.0;
+                        if (LANE < AP_NCOLS) v = prow[LANE];
+                        if (LANE < AP_NCOLS) crow[LANE] = v;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                }
+            }
+        }
+        if (LANE == 0) {
+            h_status[hrow] = status;
+            if (status == SOAP_HALO_NEED_LARGER_READ_RADIUS) {
+                h_read[hrow] = fmax(Rread * 1.5, Rsearch);   // halo_tasks.py:393-402
+                h_search[hrow] = Rsearch;
+            } else if (n_restart > 0 && status != SOAP_HALO_FATAL_SLAB_OVERFLOW) {
+                h_read[hrow] = Rread;   // the radii the reference's halo_arrays hold after the retries
+                h_search[hrow] = Rsearch;
+            }
+            h_stats[SOAP_STATS_COLUMNS * hrow + 4] = n_loop_all;
+            h_stats[SOAP_STATS_COLUMNS * hrow + 5] = n_restart + 1;
+            h_stats[SOAP_STATS_COLUMNS * hrow] = n_loop;
+            h_stats[SOAP_STATS_COLUMNS * hrow + 1] = nsel_final;
+            h_stats[SOAP_STATS_COLUMNS * hrow + 2] = ncand;
+            h_stats[SOAP_STATS_COLUMNS * hrow + 3] = P.profile == 2 ? (long long)n_have : (long long)(__builtin_readcyclecounter() - t_begin);
+        }
+    }
+}
+}  // namespace
+
+extern "C" void SOAP_CAT4(soap_launch_small_, SNS, SVAR, )(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo) {
+    hipLaunchKernelGGL(k_small, dim3(groups), dim3(64), 0, stream, params, queue, todo, n_todo);
+}

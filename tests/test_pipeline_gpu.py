@@ -19,6 +19,13 @@ from tests.test_parity_gpu import compare_halo
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _thread_group_classes_only(monkeypatch):
+    """These tests compare the pipeline with the single-kernel path of the SAME thread-group classes bit for bit; the
+    small-halo class (another order of the same sums, tests/test_small_halo_gpu.py) stays out of them."""
+    monkeypatch.setenv("SOAP_ENGINE_SMALL", "0")
+
+
 def engine_columns(engine, props, col):
     """name of the calculation a table column belongs to, and the column's offset inside its block (diagnostics)"""
     off = 0
