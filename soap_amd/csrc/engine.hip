@@ -357,6 +357,7 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b);
 SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
 // the small-halo class (small_halo.hip): one wavefront per halo, slab in LDS; variants by slab entries and chunk content
 void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
@@ -584,7 +585,9 @@ struct soap_engine {
         double ms = 0.0;
         long long nh = 0;
     } cls[3];
-    Class small;   // the small-halo class (no slab: its halos live in LDS)
+    Class small[2];   // the small-halo class (no slab: its halos live in LDS), by slab entries: 128 (all of it in LDS), 512 (streamed columns in global memory)
+    double *d_small_cols = nullptr;   // ... the latter's columns: seven per persistent wave
+    size_t small_cols_bytes = 0;
     std::vector<long long> h_nrbound;
     std::vector<unsigned long long> sort_ka, sort_kb;   // scratch of the classification sort (run)
     std::vector<unsigned> sort_rows, sort_e32;
@@ -744,11 +747,13 @@ static int32_t create_resources(soap_engine *h) {
     }
     {
         // the small-halo class shares the priority level of the wavefront class
-        if (h->own_streams) HIPCHECK(hipStreamCreateWithPriority(&h->small.stream, hipStreamNonBlocking, prio_least));
-        else HIPCHECK(hipStreamCreate(&h->small.stream));
-        HIPCHECK(hipEventCreate(&h->small.done));
-        HIPCHECK(hipEventCreate(&h->small.start));
-        HIPCHECK(hipMalloc((void **)&h->small.d_queue, sizeof(unsigned)));
+        for (int v = 0; v < 2; v++) {
+            if (h->own_streams) HIPCHECK(hipStreamCreateWithPriority(&h->small[v].stream, hipStreamNonBlocking, prio_least));
+            else HIPCHECK(hipStreamCreate(&h->small[v].stream));
+            HIPCHECK(hipEventCreate(&h->small[v].done));
+            HIPCHECK(hipEventCreate(&h->small[v].start));
+            HIPCHECK(hipMalloc((void **)&h->small[v].d_queue, sizeof(unsigned)));
+        }
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
@@ -787,11 +792,14 @@ int32_t soap_engine_destroy(soap_engine *h) {
         for (int q = 0; q < 2; q++) { if (h->cls[k].pstart[q]) (void)hipEventDestroy(h->cls[k].pstart[q]); if (h->cls[k].pdone[q]) (void)hipEventDestroy(h->cls[k].pdone[q]); }
         if (h->cls[k].stream) (void)hipStreamDestroy(h->cls[k].stream);
     }
-    if (h->small.d_queue) (void)hipFree(h->small.d_queue);
-    if (h->small.d_todo) (void)hipFree(h->small.d_todo);
-    if (h->small.done) (void)hipEventDestroy(h->small.done);
-    if (h->small.start) (void)hipEventDestroy(h->small.start);
-    if (h->small.stream) (void)hipStreamDestroy(h->small.stream);
+    for (int v = 0; v < 2; v++) {
+        if (h->small[v].d_queue) (void)hipFree(h->small[v].d_queue);
+        if (h->small[v].d_todo) (void)hipFree(h->small[v].d_todo);
+        if (h->small[v].done) (void)hipEventDestroy(h->small[v].done);
+        if (h->small[v].start) (void)hipEventDestroy(h->small[v].start);
+        if (h->small[v].stream) (void)hipStreamDestroy(h->small[v].stream);
+    }
+    if (h->d_small_cols) (void)hipFree(h->d_small_cols);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_calcs) (void)hipFree(h->d_calcs);
     if (h->d_coloff) (void)hipFree(h->d_coloff);
@@ -1269,7 +1277,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // particles (C3: 1.39 / 1.52 / 1.69 at the 10th / 50th / 90th percentile); one that does not fit after all comes back
     // with SOAP_HALO_FATAL_SLAB_OVERFLOW and is done by the wavefront class in the next pass.  Runs that need what the class
     // leaves out stay on the general path altogether.
-    std::vector<int> todo_small;
+    std::vector<int> todo_small[2];
+    const long long small_ns[2] = {128, 512};
     {
         bool small_ok = !want_inertia && !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
                         P.profile != 1 && h->cfg.slab_capacity <= 0;
@@ -1278,17 +1287,31 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         int small_mode = 1;
         { const char *e = getenv("SOAP_ENGINE_SMALL"); if (e) small_mode = atoi(e); }
         if (small_ok && small_mode != 0) {
-            const long long small_ns = 128;
             double small_factor = 1.6;
             { const char *e = getenv("SOAP_ENGINE_SMALL_FACTOR"); if (e) small_factor = atof(e); }
+            const bool use512 = !(getenv("SOAP_ENGINE_SMALL512") && atoi(getenv("SOAP_ENGINE_SMALL512")) == 0);
             std::vector<int> rest;
             rest.reserve(todo[0].size());
             for (int i : todo[0]) {
-                const bool take = small_mode == 2 || (double)h->h_nrbound[i] * small_factor + 4.0 <= (double)small_ns;   // (mode 2: every halo of the class tries, test hook)
-                (take ? todo_small : rest).push_back(i);
+                const double pred = (double)h->h_nrbound[i] * small_factor + 4.0;
+                int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : -1);
+                if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry variant)
+                if (small_mode == 3) v = 1;
+                if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
             todo[0].swap(rest);
         }
+    }
+    if (!todo_small[1].empty()) {
+        const size_t need = (size_t)(256 * 11) * 7 * (size_t)small_ns[1] * sizeof(double);
+        if (h->small_cols_bytes < need) {
+            if (h->d_small_cols) (void)hipFree(h->d_small_cols);
+            h->d_small_cols = nullptr;
+            HIPCHECK(hipMalloc((void **)&h->d_small_cols, need));
+            h->small_cols_bytes = need;
+        }
+        P.small_cols = h->d_small_cols;
+        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     TRACE("run: classified");
     const auto t_host2 = std::chrono::steady_clock::now();
@@ -1340,11 +1363,12 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         return 0;
     };
-    int groups_small = 256 * 11;   // (14 KB of LDS per wave: eleven waves per CU)
-    { const char *e = getenv("SOAP_ENGINE_GS"); if (e) groups_small = atoi(e); }
-    auto launch_small = [&](std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
+    int groups_small[2] = {256 * 11, 256 * 8};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight)
+    { const char *e = getenv("SOAP_ENGINE_GS"); if (e) groups_small[0] = groups_small[1] = atoi(e); }
+    { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
+    auto launch_small = [&](int v, std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
         if (list.empty()) return 0;
-        soap_engine::Class &C = h->small;
+        soap_engine::Class &C = h->small[v];
         const long long nt = (long long)list.size();
         if (C.todo_cap < nt) {
             if (C.d_todo) (void)hipFree(C.d_todo);
@@ -1357,7 +1381,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
         HIPCHECK(hipEventRecord(C.start, cs));
         C.nh += nt;
-        soap_launch_small_128d((int)std::min<long long>(groups_small, nt), cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        const int ng = (int)std::min<long long>(groups_small[v], nt);
+        if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        else soap_launch_small_512d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
@@ -1394,7 +1420,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipEventRecord(h->ev_p[0], st));
     TRACE("run: ev recorded");
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
-    h->small.ms = 0.0; h->small.nh = 0; h->n_small_escalated = 0;
+    for (int v = 0; v < 2; v++) { h->small[v].ms = 0.0; h->small[v].nh = 0; }
+    h->n_small_escalated = 0;
     // Hybrid (SOAP_ENGINE_PIPELINE=1): the pipeline takes the halos of the wavefront class -- nine in ten, and what saturates the GPU on
     // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
     // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
@@ -1741,7 +1768,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         h->pool.release(d_state, n * 4); h->pool.release(d_rbuild, n * 8);
     }
     TRACE("run: single-kernel part");
-    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small.size());
+    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size());
     int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
@@ -1768,13 +1795,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
-        if (only_class >= 0) for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear();   // diagnostics
+        if (only_class >= 0) { for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear(); if (only_class != 3) { todo_small[0].clear(); todo_small[1].clear(); } }   // diagnostics (3: the small-halo class)
         for (int k = 0; k < 3; k++) any = any || !todo[k].empty();
         {
             // (the small-halo class first: its waves leave room for the persistent groups of the other classes, not the other way round)
-            int rc = launch_small(todo_small, h->ev0, true);
+            int rc = 0;
+            for (int v = 0; v < 2 && !rc; v++) { rc = launch_small(v, todo_small[v], h->ev0, true); any = any || !todo_small[v].empty(); }
             if (rc) return rc;
-            any = any || !todo_small.empty();
             rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
         }
@@ -1793,7 +1820,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemcpyAsync(status.data(), h->d_status, (size_t)h->n_halo * 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         for (int k = 0; k < 3; k++) HIPCHECK(hipStreamSynchronize(h->cls[k].stream));
-        HIPCHECK(hipStreamSynchronize(h->small.stream));
+        for (int v = 0; v < 2; v++) HIPCHECK(hipStreamSynchronize(h->small[v].stream));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(-101, std::string("halo kernel: ") + hipGetErrorString(le));
         float ms = 0;
@@ -1804,14 +1831,16 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // escalate halos whose search sphere did not fit their class' slab
         std::vector<int> next[3];
         bool grow_top = false;
-        if (!todo_small.empty()) {
+        for (int v = 0; v < 2; v++) {
+            if (todo_small[v].empty()) continue;
             float m2 = 0;
-            (void)hipEventElapsedTime(&m2, h->small.start, h->small.done);
-            h->small.ms += m2;
-            for (int i : todo_small)
+            (void)hipEventElapsedTime(&m2, h->small[v].start, h->small[v].done);
+            h->small[v].ms += m2;
+            const size_t before = next[0].size();
+            for (int i : todo_small[v])
                 if (status[i] == SOAP_HALO_FATAL_SLAB_OVERFLOW) next[0].push_back(i);
-            h->n_small_escalated += (long long)next[0].size();
-            todo_small.clear();
+            h->n_small_escalated += (long long)(next[0].size() - before);
+            todo_small[v].clear();
         }
         for (int k = 0; k < 3; k++)
             for (int i : todo[k])
@@ -1842,8 +1871,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->cls[k].done, h->cls[k].stream));
             HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
         }
-        HIPCHECK(hipEventRecord(h->small.done, h->small.stream));
-        HIPCHECK(hipStreamWaitEvent(st, h->small.done, 0));
+        for (int v = 0; v < 2; v++) {
+            HIPCHECK(hipEventRecord(h->small[v].done, h->small[v].stream));
+            HIPCHECK(hipStreamWaitEvent(st, h->small[v].done, 0));
+        }
         HIPCHECK(hipEventRecord(h->ev1, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -1941,8 +1972,11 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "halo_wave")) return h->cls[0].ms;
     if (!strcmp(name, "halo_wg256")) return h->cls[1].ms;
     if (!strcmp(name, "halo_wg1024")) return h->cls[2].ms;
-    if (!strcmp(name, "halo_small")) return h->small.ms;
-    if (!strcmp(name, "n_small")) return (double)h->small.nh;
+    if (!strcmp(name, "halo_small")) return h->small[0].ms;
+    if (!strcmp(name, "halo_small512")) return h->small[1].ms;
+    if (!strcmp(name, "n_small")) return (double)(h->small[0].nh + h->small[1].nh);
+    if (!strcmp(name, "n_small128")) return (double)h->small[0].nh;
+    if (!strcmp(name, "n_small512")) return (double)h->small[1].nh;
     if (!strcmp(name, "n_small_escalated")) return (double)h->n_small_escalated;
     if (!strcmp(name, "n_wave")) return (double)h->cls[0].nh;
     if (!strcmp(name, "n_wg256")) return (double)h->cls[1].nh;

@@ -195,6 +195,9 @@ struct RunParams {
     int *gbins;                   // radial bins of the giants' build (GBuild.bin_first)
     double rebuild_factor;        // a halo whose loop ran past its superset is rebuilt out to this times the radius it asked for
     int g_coarse;                 // test hook (SOAP_ENGINE_G_COARSE=1): four buckets per large halo, so that every bucket outgrows its LDS block
+    double *small_cols;           // small-halo class with its streamed columns in global memory: seven columns of slab entries per wave
+    int *small_esc;               // small-halo class: [0] number of rows in the list behind it -- halos that outgrew the class' slab are appended
+                                  // and done by the wavefront class, launched behind the small-halo kernels with this list (null: status only)
 };
 
 // ------------------------------------------------------------------------------------------

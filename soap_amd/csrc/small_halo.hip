@@ -32,6 +32,9 @@
 #define SHYDRO 0
 #endif
 #define SE (SNS / 64)          // slab entries per lane: entry i belongs to lane i & 63, register slot i >> 6
+#ifndef SGLOBAL
+#define SGLOBAL 0              // 1: the columns that only the property passes stream (mass, offsets, velocities: 56 of the 81 bytes of an
+#endif                         // entry) live in a slice of global memory that belongs to the wave, the slab of a 512-entry halo takes 11 KB of LDS
 #define SPREFB 12              // calculations whose prefix moments are finalised together
 #if SHYDRO
 #define SMOM A_NSUM
@@ -62,7 +65,12 @@ namespace {
 
 struct SmallWave {
     // the slab, sorted by radius once it is built
-    double r[SNS], cum[SNS], m[SNS], dx[SNS], dy[SNS], dz[SNS], vx[SNS], vy[SNS], vz[SNS];
+    double r[SNS], cum[SNS];
+#if !SGLOBAL
+    double m[SNS], dx[SNS], dy[SNS], dz[SNS], vx[SNS], vy[SNS], vz[SNS];
+#else
+    GAS double *cols;             // this wave's slice of RunParams.small_cols: seven columns of SNS doubles
+#endif
     unsigned pidx[SNS];
     unsigned char flags[SNS];
     // stage B
@@ -87,6 +95,14 @@ __shared__ SmallWave g_W;
 #endif
 #define g_S g_W
 #define LANE ((int)(threadIdx.x & 63))
+
+// the streamed columns of the slab
+#if SGLOBAL
+enum { SC_m = 0, SC_dx, SC_dy, SC_dz, SC_vx, SC_vy, SC_vz, SC_NCOLS };
+#define CX(name) (small_cols_base() + SC_##name * SNS)
+#else
+#define CX(name) g_W.name
+#endif
 
 // LDS traffic between the lanes of ONE wave: its LDS instructions execute in order, so only the compiler has to be kept
 // from moving accesses across the hand-over (no s_waitcnt on outstanding global loads, unlike a workgroup-scope fence)
@@ -114,6 +130,14 @@ SOAP_DEV long long uni(long long v) {
     const unsigned lo = (unsigned)uni((int)(unsigned)v), hi = (unsigned)uni((int)(unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
+
+#if SGLOBAL
+SOAP_DEV GAS double *small_cols_base() {   // (uniform: an SGPR pair)
+    const unsigned long long v = (unsigned long long)g_W.cols;
+    const unsigned lo = (unsigned)uni((int)(unsigned)v), hi = (unsigned)uni((int)(unsigned)(v >> 32));
+    return (GAS double *)(((unsigned long long)hi << 32) | lo);
+}
+#endif
 
 // enclosed density of slab entry i as materialize() of halo_kernel.inc tabulates it (SO_properties.py:404-406, :420)
 SOAP_DEV double small_dens(int i) {
@@ -365,6 +389,139 @@ __device__ __forceinline__ void small_sort(double (&k)[SE], unsigned (&v)[SE], u
 // Returns the number of entries (>= 0), -1 if the sphere does not fit the slab.  q[e] receives the minimum-image r^2 of the
 // lane's entries (for the spheres of the radius rounds); g_W.shift / *fof0 the velocity and the FOF id of the innermost
 // particle (SO_properties.py:407-409).
+#if SGLOBAL
+// The variant with the streamed columns in global memory: the selected particles' coordinates are read once more from the
+// cell-ordered arrays (the lines the selection has just streamed), the (radius, index) pairs are sorted in registers, and the
+// payload records are then gathered IN SORTED ORDER, every column written once at its final place.
+__device__ __forceinline__ int small_build(const CAS RunParams &P, double R, long long hindex, double (&q)[SE], long long *fof0) {
+    const int n = small_select(P, R);
+    if (n < 0) return -1;
+    WSYNC();
+    const double cx = g_W.c[0], cy = g_W.c[1], cz = g_W.c[2], L = g_W.L;
+    double key[SE];
+    unsigned pv[SE], sl[SE];
+    // ---- radii of the selected particles
+    {
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            const int i = 64 * e + LANE;
+            key[e] = INFINITY; pv[e] = 0xffffffffu; sl[e] = 0u;
+            if (i < n) pv[e] = g_W.pidx[i];
+        }
+        double xx[SE], yy[SE], zz[SE];
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            xx[e] = yy[e] = zz[e] = 0.0;
+            if (64 * e + LANE < n) {
+                const unsigned p = pv[e] & PIDX_MASK;
+#if SHYDRO
+                const int ts = (int)(pv[e] >> PIDX_BITS);
+                const CAS TypeDev &T = P.t[ts];
+#else
+                const CAS TypeDev &T = P.t[1];
+#endif
+                xx[e] = ((const GAS double *)T.x)[p]; yy[e] = ((const GAS double *)T.y)[p]; zz[e] = ((const GAS double *)T.z)[p];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            if (64 * e + LANE < n) {
+                const double wx = wrap_rel(xx[e], cx, L), wy = wrap_rel(yy[e], cy, L), wz = wrap_rel(zz[e], cz, L);
+                key[e] = sqrt((wx * wx + wy * wy) + wz * wz);
+            }
+        }
+    }
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    small_sort(key, pv, sl, lg);
+    WSYNC();
+#pragma unroll
+    for (int e = 0; e < SE; e++) if (64 * e + LANE < n) { g_W.r[64 * e + LANE] = key[e]; g_W.pidx[64 * e + LANE] = pv[e]; }
+    WSYNC();
+    const GAS Pay *pay0 = (const GAS Pay *)P.t[0].pay, *pay1 = (const GAS Pay *)P.t[1].pay, *pay2 = (const GAS Pay *)P.t[2].pay,
+                  *pay3 = (const GAS Pay *)P.t[3].pay;
+    // ---- the innermost particle (no neutrinos in this class: entry 0): FOF id, velocity shift -- every lane reads its record
+    long long f0 = -1;
+    double sh0 = 0.0, sh1 = 0.0, sh2 = 0.0;
+    {
+        const unsigned pi0 = n > 0 ? g_W.pidx[0] : 0u;
+#if SHYDRO
+        const int ts0 = (int)(pi0 >> PIDX_BITS);
+        const GAS Pay *base0 = ts0 == 0 ? pay0 : (ts0 == 1 ? pay1 : (ts0 == 2 ? pay2 : pay3));
+#else
+        const GAS Pay *base0 = pay1;
+#endif
+        if (n > 0) {
+            const Pay r0 = load_pay(base0 + (pi0 & PIDX_MASK));
+            f0 = uni(r0.fof); sh0 = uni(r0.vx); sh1 = uni(r0.vy); sh2 = uni(r0.vz);
+        }
+    }
+    *fof0 = f0;
+    if (LANE == 0) { g_W.shift[0] = sh0; g_W.shift[1] = sh1; g_W.shift[2] = sh2; }
+    // ---- the payload records in sorted order, two entries per lane in flight
+    GAS double *c_m = CX(m), *c_dx = CX(dx), *c_dy = CX(dy), *c_dz = CX(dz), *c_vx = CX(vx), *c_vy = CX(vy), *c_vz = CX(vz);
+#pragma unroll
+    for (int e0 = 0; e0 < SE; e0 += 2) {
+        Pay rec[2];
+        int ts[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = e0 + u, i = 64 * e + LANE;
+            ts[u] = 1;
+            if (i < n) {
+                ts[u] = (int)(pv[e] >> PIDX_BITS);
+#if SHYDRO
+                const GAS Pay *base = ts[u] == 0 ? pay0 : (ts[u] == 1 ? pay1 : (ts[u] == 2 ? pay2 : pay3));
+#else
+                const GAS Pay *base = pay1;
+#endif
+                rec[u] = load_pay(base + (pv[e] & PIDX_MASK));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = e0 + u, i = 64 * e + LANE;
+            q[e] = INFINITY;
+            if (i < n) {
+                const Pay &R_ = rec[u];
+                const double wx = wrap_rel(R_.x, cx, L), wy = wrap_rel(R_.y, cy, L), wz = wrap_rel(R_.z, cz, L);
+                const double ax = min_image(R_.x, cx, L), ay = min_image(R_.y, cy, L), az = min_image(R_.z, cz, L);
+                q[e] = (ax * ax + ay * ay) + az * az;
+                c_dx[i] = wx; c_dy[i] = wy; c_dz[i] = wz;
+                c_vx[i] = R_.vx - sh0; c_vy[i] = R_.vy - sh1; c_vz[i] = R_.vz - sh2;
+                c_m[i] = R_.m;
+                g_W.cum[i] = R_.m;   // (the cumulative-mass chain below runs in place)
+                unsigned char fl = (unsigned char)ts[u];
+                if (R_.grnr == hindex) fl |= FL_BOUND;
+                if (R_.grnr >= 0 && R_.grnr != hindex) fl |= (R_.fof == f0) ? FL_SAT : FL_EXT;
+                g_W.flags[i] = fl;
+            }
+        }
+    }
+    (void)pay0; (void)pay2; (void)pay3;
+    // the columns are read back by other lanes of the wave (shell ranges of the flow rates): global memory, workgroup scope
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    WSYNC();
+    // ---- cumulative mass in numpy.cumsum order: ONE sequential chain, in place over the masses parked in the column
+    if (LANE == 0) {
+        double run = 0.0;
+        int j = 0;
+        for (; j + 16 <= n; j += 16) {
+            double a_[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) a_[u] = g_W.cum[j + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { run += a_[u]; a_[u] = run; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) g_W.cum[j + u] = a_[u];
+        }
+        for (; j < n; j++) { run += g_W.cum[j]; g_W.cum[j] = run; }
+    }
+    WSYNC();
+    return n;
+}
+#else
 __device__ __forceinline__ int small_build(const CAS RunParams &P, double R, long long hindex, double (&q)[SE], long long *fof0) {
 #ifndef NO_SEL
     const int n = small_select(P, R);
@@ -494,6 +651,8 @@ __device__ __forceinline__ int small_build(const CAS RunParams &P, double R, lon
     return n;
 }
 
+#endif   // SGLOBAL
+
 // order the calculations of one family by prefix length (lanes = calculations): returns how many there are, *rank this
 // lane's position (or -1); g_W.bnd[k] the k-th prefix length
 __device__ __forceinline__ int small_family_order(bool in, int nc, int *rank_out) {
@@ -561,9 +720,9 @@ __device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_fa
                 if (i < nmax) {
                     const unsigned char fl = g_W.flags[i];
                     if (!bound_family || (fl & FL_BOUND)) {
-                        const double mm = g_W.m[i], r = g_W.r[i];
-                        const double x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i];
-                        const double u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+                        const double mm = CX(m)[i], r = g_W.r[i];
+                        const double x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i];
+                        const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i];
                         c[0] = 1.0; c[1] = mm;
                         c[2] = mm * x; c[3] = mm * y; c[4] = mm * z;
                         c[5] = mm * u; c[6] = mm * v; c[7] = mm * w;
@@ -606,8 +765,8 @@ __device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_fa
                 if (i < nmax) {
                     const unsigned char fl = g_W.flags[i];
                     if (!bound_family || (fl & FL_BOUND)) {
-                        const double mm = g_W.m[i], r = g_W.r[i];
-                        const double u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+                        const double mm = CX(m)[i], r = g_W.r[i];
+                        const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i];
                         c[0] = mm * u * u; c[1] = mm * v * v; c[2] = mm * w * w;
                         c[3] = mm * u * v; c[4] = mm * u * w; c[5] = mm * v * w;
                         c[6] = mm * fmax(soft1, r);
@@ -693,7 +852,7 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
             const unsigned char fl = g_W.flags[i];
             mem = !bound_family || (fl & FL_BOUND);
             t = fl & FL_TYPE;
-            if (mem) { mm = g_W.m[i]; r = g_W.r[i]; }
+            if (mem) { mm = CX(m)[i]; r = g_W.r[i]; }
         }
         const double sA = wave_scan(mm, LANE) + carryA;
 #if SHYDRO
@@ -725,7 +884,10 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
             if (j >= 0 && j < 64) { my_vs = bv; my_rs = bs; }
         }
         // ---- half-mass crossings
-        const double pA = LANE == 0 ? carryA : dpp_f64<DPP_WAVE_SHR1>(sA), pB = LANE == 0 ? carryB : dpp_f64<DPP_WAVE_SHR1>(sB);
+        // (the shifts BEFORE the lane-dependent choice: inside its branch lane 0 is switched off, and a DPP move whose source lane
+        // is switched off delivers zero -- lane 1 would see no mass before it)
+        const double shA = dpp_f64<DPP_WAVE_SHR1>(sA), shB = dpp_f64<DPP_WAVE_SHR1>(sB);
+        const double pA = LANE == 0 ? carryA : shA, pB = LANE == 0 ? carryB : shB;
 #pragma unroll
         for (int w = 0; w < SNHM; w++) {
             unsigned long long open = __ballot(in && tg[w] > 0.0 && my_n > base);
@@ -789,7 +951,7 @@ __device__ __forceinline__ void small_subhalo_spin(GAS double *row, int n0, doub
     for (int e = 0; e < SE; e++) {
         const int i = 64 * e + LANE;
         if (i < n0 && (g_W.flags[i] & FL_BOUND) && g_W.r[i] <= rmax_s) {
-            const double mm = g_W.m[i], x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i], u = g_W.vx[i], v = g_W.vy[i], w = g_W.vz[i];
+            const double mm = CX(m)[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i], u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i];
             sm += mm; mx0 += mm * x; mx1 += mm * y; mx2 += mm * z;
             l0 += mm * (y * w - z * v); l1 += mm * (z * u - x * w); l2 += mm * (x * v - y * u);
         }
@@ -844,7 +1006,7 @@ __device__ __forceinline__ void small_flow_one(const CAS RunParams &P, GAS doubl
 #pragma unroll
         for (int k = 0; k < 10; k++) a[k] = 0.0;
         for (int i = LANE; i < k30; i += 64) {
-            const double mm = g_W.m[i], ux = g_W.vx[i], uy = g_W.vy[i], uz = g_W.vz[i];
+            const double mm = CX(m)[i], ux = CX(vx)[i], uy = CX(vy)[i], uz = CX(vz)[i];
             const double mx = mm * ux, my = mm * uy, mz = mm * uz;
             const bool in10 = i < k10;
             a[0] += in10 ? mm : 0.0; a[1] += in10 ? mx : 0.0; a[2] += in10 ? my : 0.0; a[3] += in10 ? mz : 0.0;
@@ -882,9 +1044,9 @@ __device__ __forceinline__ void small_flow_one(const CAS RunParams &P, GAS doubl
         const int sh = (j >= off[1] ? 1 : 0) + (j >= off[2] ? 1 : 0);
         const int i = j + (sh == 0 ? base[0] : (sh == 1 ? base[1] : base[2]));
         const unsigned char tf = g_W.flags[i];
-        const double rr = g_W.r[i], mm = g_W.m[i];
-        const double x = g_W.dx[i], y = g_W.dy[i], z = g_W.dz[i];
-        const double ux = g_W.vx[i], uy = g_W.vy[i], uz = g_W.vz[i];
+        const double rr = g_W.r[i], mm = CX(m)[i];
+        const double x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i];
+        const double ux = CX(vx)[i], uy = CX(vy)[i], uz = CX(vz)[i];
         const double vc0 = sh == 0 ? vc[0][0] : (sh == 1 ? vc[1][0] : vc[2][0]);
         const double vc1 = sh == 0 ? vc[0][1] : (sh == 1 ? vc[1][1] : vc[2][1]);
         const double vc2 = sh == 0 ? vc[0][2] : (sh == 1 ? vc[1][2] : vc[2][2]);
@@ -936,6 +1098,9 @@ k_small(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo)
     if (LANE == 0) {
         g_W.L = P.boxsize; g_W.nu_density = P.nu_density; g_W.a = P.a; g_W.mpc = P.mpc; g_W.mpc20 = P.mpc20; g_W.G_eff = P.G_eff;
         g_W.hydro = P.hydro; g_W.has_nu = P.has_nu;
+#if SGLOBAL
+        g_W.cols = (GAS double *)P.small_cols + (long long)blockIdx.x * (SC_NCOLS * SNS);
+#endif
 #ifdef SMALL_CHECK
         g_W.dbg = (unsigned long long *)P.phase;
 #endif

@@ -28,8 +28,8 @@ class _NoInertia:
 
 
 def _run(engine, props, sc, halos_np, small, monkeypatch, resident=None, groups=None):
-    """small: 0 the general path only; 1 the default split; 2 every halo of the wavefront class tries the small class first
-    (those that do not fit are escalated)"""
+    """small: 0 the general path only; 1 the default split; 2 / 3 every halo of the wavefront class tries the small class first,
+    its 128-entry / 512-entry variant (those that do not fit are escalated)"""
     monkeypatch.setenv("SOAP_ENGINE_SMALL", str(small))
     if groups is not None:
         monkeypatch.setenv("SOAP_ENGINE_GS", str(groups))
@@ -74,6 +74,11 @@ def test_small_class_matches_the_oracle_and_the_general_path(built_library, monk
     assert n2 > n1 and e2 > 0, (n1, n2, e2)
     _same_selections(ha2, raw2, ha0, raw0)
     assert _close(t2, t0)
+    # ... and through the variant with 512 slab entries (its streamed columns in global memory)
+    ha6, res6, raw6, t6, (n6, e6) = _run(engine, props, sc, halos_np, 3, monkeypatch)
+    assert n6 >= n2 and e6 < e2, (n2, n6, e2, e6)
+    _same_selections(ha6, raw6, ha0, raw0)
+    assert _close(t6, t0)
     # few persistent waves: every wave works through many halos
     ha3, _, raw3, t3, (n3, _) = _run(engine, props, sc, halos_np, 1, monkeypatch, groups=3)
     assert n3 == n1 and np.array_equal(t3, t1)
@@ -103,6 +108,7 @@ def test_small_class_matches_the_oracle_and_the_general_path(built_library, monk
         o = {k: v for k, v in ref[row].items() if "InertiaTensor" not in k}
         compare_halo(o, res1[j], sc)
         compare_halo(o, res2[j], sc)
+        compare_halo(o, res6[j], sc)
     st = raw1["stats"][raw1["status"] == 0]
     assert np.array_equal(st[:, 0], [s["n_loop"] for s in stats])
     assert np.array_equal(st[:, 1], [s["n_sel"] for s in stats])
