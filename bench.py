@@ -443,6 +443,7 @@ def main():
             "catalogue_bytes_per_halo": {"stored": packed.bytes_per_halo(), "fp64_table": 8 * packed.table_columns},
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
                           "reorder": float(np.mean(ms_reorder)),
+                          "halo_small128": engine.kernel_ms("halo_small"), "halo_small512": engine.kernel_ms("halo_small512"),
                           "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),
                           "halo_wg1024": engine.kernel_ms("halo_wg1024"),
                           "pipe_build": engine.kernel_ms("pipe_build"), "pipe_stage_a": engine.kernel_ms("pipe_stage_a"),
@@ -453,6 +454,10 @@ def main():
             "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
             "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
                                 int(engine.kernel_ms("n_wg1024"))],
+            # the small-halo class (one wavefront per halo, slab in LDS): halos that went through its 128- / 512-entry kernels, and
+            # how many of them were handed on to the wavefront class (counted there too)
+            "halos_small_class": {"slab128": int(engine.kernel_ms("n_small128")), "slab512": int(engine.kernel_ms("n_small512")),
+                                  "handed_on": int(engine.kernel_ms("n_small_escalated"))},
             **({"phase_cycles": engine.phase_cycles()} if os.environ.get("SOAP_ENGINE_PROFILE") == "1" else {}),   # diagnostics
             "roofline": {
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -587,6 +587,8 @@ struct soap_engine {
     } cls[3];
     Class small[2];   // the small-halo class (no slab: its halos live in LDS), by slab entries: 128 (all of it in LDS), 512 (streamed columns in global memory)
     double *d_small_cols = nullptr;   // ... the latter's columns: seven per persistent wave
+    int *d_small_esc = nullptr;       // [0] count, then the rows the small-halo kernels hand on to the wavefront class
+    size_t small_esc_count = 0;
     size_t small_cols_bytes = 0;
     std::vector<long long> h_nrbound;
     std::vector<unsigned long long> sort_ka, sort_kb;   // scratch of the classification sort (run)
@@ -800,6 +802,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
         if (h->small[v].stream) (void)hipStreamDestroy(h->small[v].stream);
     }
     if (h->d_small_cols) (void)hipFree(h->d_small_cols);
+    if (h->d_small_esc) (void)hipFree(h->d_small_esc);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_calcs) (void)hipFree(h->d_calcs);
     if (h->d_coloff) (void)hipFree(h->d_coloff);
@@ -1284,7 +1287,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                         P.profile != 1 && h->cfg.slab_capacity <= 0;
         for (int c = 0; c < n_calcs; c++)
             if (calcs[c].kind == SOAP_CALC_PROJECTED || (calcs[c].flags & SOAP_CALC_FLAG_ROTATION)) small_ok = false;
-        int small_mode = 1;
+        // SOAP_ENGINE_SMALL: 0 off; 4 (default) EVERY halo of the wavefront class goes through the small-halo kernels -- the
+        // 128-entry one where the bound-particle count says so, the 512-entry one otherwise -- and what does not fit is handed on
+        // (C3: 17.5 ms of halo kernels against 20.3 with the larger halos on the wavefront class from the start: its 2048
+        // persistent waves hold the LDS the small-halo kernels wait for); 1 only the halos that are expected to fit; 2 / 3 test hooks
+        int small_mode = 4;
         { const char *e = getenv("SOAP_ENGINE_SMALL"); if (e) small_mode = atoi(e); }
         if (small_ok && small_mode != 0) {
             double small_factor = 1.6;
@@ -1297,10 +1304,24 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : -1);
                 if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry variant)
                 if (small_mode == 3) v = 1;
+                if (small_mode == 4 && v < 0) v = 1;   // (every halo of the class through the small-halo kernels: what does not fit is handed on)
                 if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
             todo[0].swap(rest);
         }
+    }
+    static const bool small_handover = !(getenv("SOAP_ENGINE_SMALL_HANDOVER") && atoi(getenv("SOAP_ENGINE_SMALL_HANDOVER")) == 0);
+    if (small_handover && (!todo_small[0].empty() || !todo_small[1].empty())) {
+        // halos that outgrow the small-halo class are handed on inside the pass: list on the device, filled by its kernels
+        if (h->small_esc_count < (size_t)h->n_halo + 1) {
+            if (h->d_small_esc) (void)hipFree(h->d_small_esc);
+            h->d_small_esc = nullptr;
+            h->small_esc_count = (size_t)h->n_halo + 1 + (size_t)h->n_halo / 4;
+            HIPCHECK(hipMalloc((void **)&h->d_small_esc, h->small_esc_count * sizeof(int)));
+        }
+        P.small_esc = h->d_small_esc;
+        HIPCHECK(hipMemsetAsync(h->d_small_esc, 0, sizeof(int), st));
+        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     if (!todo_small[1].empty()) {
         const size_t need = (size_t)(256 * 11) * 7 * (size_t)small_ns[1] * sizeof(double);
@@ -1798,12 +1819,33 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (only_class >= 0) { for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear(); if (only_class != 3) { todo_small[0].clear(); todo_small[1].clear(); } }   // diagnostics (3: the small-halo class)
         for (int k = 0; k < 3; k++) any = any || !todo[k].empty();
         {
-            // (the small-halo class first: its waves leave room for the persistent groups of the other classes, not the other way round)
+            // the thread-group classes first, largest groups first: a 1024-thread group needs an empty CU, and the waves of the
+            // small-halo class (three per SIMD fill its registers) would never leave one
+            static const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
             int rc = 0;
-            for (int v = 0; v < 2 && !rc; v++) { rc = launch_small(v, todo_small[v], h->ev0, true); any = any || !todo_small[v].empty(); }
+            if (small_first) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
             if (rc) return rc;
             rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
+            if (!small_first) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
+            if (rc) return rc;
+            for (int v = 0; v < 2; v++) any = any || !todo_small[v].empty();
+            if (P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) {
+                // behind the small-halo kernels (and behind the wavefront class' own launch of this pass: same stream, same
+                // slab): the wavefront class once more, for the rows that were handed on
+                soap_engine::Class &C = h->cls[0];
+                hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
+                int rc2 = alloc_slab(C, caps[0], groups[0]);
+                if (rc2) return rc2;
+                for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(cs, h->small[v].done, 0));
+                HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+                const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size()));
+                if (todo[0].empty()) HIPCHECK(hipEventRecord(C.start, cs));
+                if (!want_inertia) soap_launch_halo_64n(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+                else soap_launch_halo_64i(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+                HIPCHECK(hipEventRecord(C.done, cs));
+                HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+            }
         }
         if (pass == 0) {
             // the large halos launched before the pipeline stages: their statuses are checked with this pass
@@ -1831,15 +1873,41 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // escalate halos whose search sphere did not fit their class' slab
         std::vector<int> next[3];
         bool grow_top = false;
+        if (pass == 0 && P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) {
+            int nesc = 0;
+            HIPCHECK(hipMemcpy(&nesc, h->d_small_esc, sizeof(int), hipMemcpyDeviceToHost));
+            h->n_small_escalated += nesc;
+            h->cls[0].nh += nesc;
+            if (trace) {
+                std::vector<int> rows((size_t)std::max(nesc, 0));
+                if (nesc > 0) (void)hipMemcpy(rows.data(), h->d_small_esc + 1, (size_t)nesc * sizeof(int), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[soap_engine] small-halo class handed on %d rows:", nesc);
+                for (int q = 0; q < std::min(nesc, 24); q++) fprintf(stderr, " %d(nb %lld)", rows[q], rows[q] >= 0 && rows[q] < h->n_halo ? h->h_nrbound[rows[q]] : -1ll);
+                {
+                    std::vector<int> srt(rows); std::sort(srt.begin(), srt.end());
+                    int dup = 0; for (size_t q = 1; q < srt.size(); q++) dup += srt[q] == srt[q - 1];
+                    std::vector<char> in0(h->n_halo, 0), in1(h->n_halo, 0), inc(h->n_halo, 0);
+                    for (int i : todo_small[0]) in0[i] = 1; for (int i : todo_small[1]) in1[i] = 1; for (int i : todo[0]) inc[i] = 1;
+                    int c0 = 0, c1 = 0, cc = 0, other = 0;
+                    for (int r : rows) { if (r < 0 || r >= h->n_halo) { other++; continue; } c0 += in0[r]; c1 += in1[r]; cc += inc[r]; if (!in0[r] && !in1[r] && !inc[r]) other++; }
+                    fprintf(stderr, "\n[soap_engine]   duplicates %d; of the 128-entry list %d (of %zu), of the 512-entry list %d (of %zu), of the wavefront class' own list %d (of %zu), other %d", dup, c0, todo_small[0].size(), c1, todo_small[1].size(), cc, todo[0].size(), other);
+                }
+                fprintf(stderr, "\n");
+            }
+            float m2 = 0;
+            if (todo[0].empty()) { (void)hipEventElapsedTime(&m2, h->cls[0].start, h->cls[0].done); h->cls[0].ms += m2; }
+        }
         for (int v = 0; v < 2; v++) {
             if (todo_small[v].empty()) continue;
             float m2 = 0;
             (void)hipEventElapsedTime(&m2, h->small[v].start, h->small[v].done);
             h->small[v].ms += m2;
-            const size_t before = next[0].size();
+            // (handed on inside the pass: a row that still overflows has outgrown the wavefront class' slab too)
+            std::vector<int> &nx = P.small_esc != nullptr ? next[1] : next[0];
+            const size_t before = nx.size();
             for (int i : todo_small[v])
-                if (status[i] == SOAP_HALO_FATAL_SLAB_OVERFLOW) next[0].push_back(i);
-            h->n_small_escalated += (long long)(next[0].size() - before);
+                if (status[i] == SOAP_HALO_FATAL_SLAB_OVERFLOW) nx.push_back(i);
+            if (P.small_esc == nullptr) h->n_small_escalated += (long long)(nx.size() - before);
             todo_small[v].clear();
         }
         for (int k = 0; k < 3; k++)

@@ -1471,6 +1471,11 @@ k_small(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo)
                 }
             }
         }
+        if (status == SOAP_HALO_FATAL_SLAB_OVERFLOW && LANE == 0) {
+            // handed on: the wavefront class of halo_kernel.inc is launched behind this kernel with the list these rows go to
+            GAS int *esc = (GAS int *)P.small_esc;
+            if (esc != nullptr) { const int slot = atomicAdd((int *)esc, 1); esc[1 + slot] = (int)hrow; }
+        }
         if (LANE == 0) {
             h_status[hrow] = status;
             if (status == SOAP_HALO_NEED_LARGER_READ_RADIUS) {

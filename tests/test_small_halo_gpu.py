@@ -28,8 +28,9 @@ class _NoInertia:
 
 
 def _run(engine, props, sc, halos_np, small, monkeypatch, resident=None, groups=None):
-    """small: 0 the general path only; 1 the default split; 2 / 3 every halo of the wavefront class tries the small class first,
-    its 128-entry / 512-entry variant (those that do not fit are escalated)"""
+    """small: 0 the general path only; 1 only the halos that are expected to fit go through the small class; 2 / 3 every halo of the
+    wavefront class tries its 128-entry / 512-entry variant first; 4 (the default) the variant the bound-particle count suggests (what
+    does not fit is handed on to the wavefront class inside the pass)"""
     monkeypatch.setenv("SOAP_ENGINE_SMALL", str(small))
     if groups is not None:
         monkeypatch.setenv("SOAP_ENGINE_GS", str(groups))
@@ -79,6 +80,11 @@ def test_small_class_matches_the_oracle_and_the_general_path(built_library, monk
     assert n6 >= n2 and e6 < e2, (n2, n6, e2, e6)
     _same_selections(ha6, raw6, ha0, raw0)
     assert _close(t6, t0)
+    # the default: every halo of the wavefront class through the variant its bound-particle count suggests
+    ha7, res7, raw7, t7, (n7, e7) = _run(engine, props, sc, halos_np, 4, monkeypatch)
+    assert n7 >= n2, (n2, n7)
+    _same_selections(ha7, raw7, ha0, raw0)
+    assert _close(t7, t0)
     # few persistent waves: every wave works through many halos
     ha3, _, raw3, t3, (n3, _) = _run(engine, props, sc, halos_np, 1, monkeypatch, groups=3)
     assert n3 == n1 and np.array_equal(t3, t1)
