@@ -355,6 +355,8 @@ def main():
         if record:
             ms_halo.append(t_h)
         state["nleft"] = int(np.sum(ha["done"] == 0))
+        if state["nleft"]:   # (the chunk loop of the reference runs until no halo is left: a pass that leaves some is not a measurement)
+            raise RuntimeError(f"{state['nleft']} halos unfinished after 8 read-radius iterations")
         state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
                             radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
         # final catalogue: concatenation over the ranks in (cell, catalogue index) order

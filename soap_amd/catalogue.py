@@ -141,24 +141,3 @@ def gather_catalogue_packed(narrow: torch.Tensor, wide: torch.Tensor, cofp: torc
     cofp_all = got_w[:, 1:4].contiguous()
     o = order_of(cofp_all, index_all)
     return got_n[o], got_w[o, 4:], cofp_all[o], index_all[o]
-
-
-def partition_halos(cofp: np.ndarray, n_chunks: int, boxsize: float, bits: int = 10):
-    """
-    Assign halos to `n_chunks` spatially compact, equal-count chunks by sorting the centres
-    along a space-filling curve, as the reference's Peano-Hilbert decomposition does
-    (SOAP/core/domain_decomposition.py:64-142; its key comes from virgo.util.peano, which is
-    not in the reference tree -- we use a Morton key of the same 10 bits per dimension: chunk
-    membership differs from the reference's, per-halo results do not depend on it).
-    Returns chunk id per halo.
-    """
-    n = cofp.shape[0]
-    ipos = np.clip((cofp / boxsize * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
-    key = np.zeros(n, dtype=np.int64)
-    for b in range(bits):
-        for d in range(3):
-            key |= ((ipos[:, d] >> b) & 1) << (3 * b + (2 - d))
-    order = np.argsort(key, kind="stable")
-    chunk = np.empty(n, dtype=np.int64)
-    chunk[order] = (np.arange(n) * n_chunks) // max(n, 1)
-    return chunk

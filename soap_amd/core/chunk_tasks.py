@@ -284,6 +284,12 @@ def run_chunk_task(engine, snapshot: SnapshotCells, halo_prop_list: List, cellgr
         if log is not None:
             log.append(dict(iteration=it, cells=nr_cells, particles=nr_parts, done=int(ok.sum()), left=out[2]))
         data = None   # a further iteration reads the (larger) region of the halos that are left
+    nleft = int(np.sum(halo_arrays["done"] == 0))
+    if nleft:
+        # the reference loops until no halo is left (chunk_tasks.py:189-367); a catalogue that silently misses rows is worse
+        # than no catalogue
+        raise RuntimeError(f"{nleft} halos still ask for a larger read radius after {max_iterations} iterations "
+                           f"(first catalogue index: {int(np.asarray(halo_arrays['index'])[halo_arrays['done'] == 0][0])})")
     return rs
 
 

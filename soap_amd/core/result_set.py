@@ -230,12 +230,15 @@ def _cast(raw, prop, a):
     return out[:, 0] if prop.shape == 1 else out
 
 
-def run_chunk(engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, max_passes: int = 8) -> ResultSet:
+def run_chunk(engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, max_passes: int = 8, allow_unfinished: bool = False) -> ResultSet:
     """
     Process every halo of a staged chunk: repeat `process_halos` while halos ask for a larger read radius
     (chunk_tasks.py:306-340: the reference re-reads a larger region and calls process_halos again; here
     the chunk's particles are already resident, so a pass just re-runs the unfinished halos with the radii
-    the engine returned).  Returns the ResultSet of all finished halos; `halo_arrays["done"]` tells which.
+    the engine returned).  Returns the ResultSet of all finished halos.  A halo that is still not done at the end -- its read
+    radius has outgrown what is staged, or `max_passes` is spent -- is an error (the reference loops until none is left; a
+    catalogue with rows missing silently is worse than none) unless `allow_unfinished` says the caller looks at
+    `halo_arrays["done"]` itself.
     """
     from . import halo_tasks
 
@@ -254,4 +257,7 @@ def run_chunk(engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, max_pas
             rs.append_table(table, {k: np.asarray(halo_arrays[k])[rows] for k in _INPUT_HALO_COLUMNS})
         if int(np.sum(halo_arrays["done"])) == before and not np.any(raw["status"] == halo_tasks.STATUS_NEED_LARGER_READ_RADIUS):
             break
+    nleft = int(np.sum(halo_arrays["done"] == 0))
+    if nleft and not allow_unfinished:
+        raise RuntimeError(f"{nleft} halos of the staged chunk are not finished after {max_passes} passes")
     return rs

@@ -20,15 +20,21 @@ def _worker(rank, world, port, tmpdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from soap_amd.catalogue import gather_catalogue, partition_halos, spatial_sort_order
+    from soap_amd.catalogue import gather_catalogue, spatial_sort_order
+    from soap_amd.core.chunk_tasks import split_halos
 
     rng = np.random.default_rng(99)
     n, ncols, L = 137, 11, 100.0
     cofp = rng.uniform(0, L, (n, 3))
     index = rng.permutation(n).astype(np.int64) * 3 + 1
     table = rng.normal(size=(n, ncols))
-    chunk = partition_halos(cofp, world, L)
-    mine = chunk == rank
+    # the product's own split: Peano-Hilbert chunks of the halo table (chunk_tasks.split_halos, what bench.py --gpus N
+    # and run_chunk_task use), every rank takes its chunk
+    halos = dict(index=index, cofp=cofp, nr_bound_part=rng.integers(20, 5000, n), row=np.arange(n))
+    chunks = split_halos(halos, L, world)
+    assert sum(len(c["index"]) for c in chunks) == n and abs(len(chunks[0]["index"]) - len(chunks[1]["index"])) <= 1
+    mine = np.zeros(n, dtype=bool)
+    mine[chunks[rank]["row"]] = True
     assert 0 < mine.sum() < n
     t, c, i = gather_catalogue(torch.from_numpy(table[mine]), torch.from_numpy(cofp[mine]),
                                torch.from_numpy(index[mine]), cell_size=L / 4, dimension=(4, 4, 4))  # fmt: skip
@@ -57,15 +63,20 @@ def test_catalogue_gather_two_ranks(tmp_path):
     assert np.array_equal(a, b) and len(a) == 137
 
 
-def test_partition_is_balanced_and_compact():
+def test_split_is_balanced_and_compact():
+    """the split the ranks use (Peano-Hilbert keys, equal counts: domain_decomposition.py:64-142)"""
     sys.path.insert(0, ROOT)
-    from soap_amd.catalogue import partition_halos
+    from soap_amd.core.chunk_tasks import split_halos
 
     rng = np.random.default_rng(5)
     cofp = rng.uniform(0, 50.0, (8000, 3))
-    chunk = partition_halos(cofp, 8, 50.0)
-    counts = np.bincount(chunk, minlength=8)
+    halos = dict(index=np.arange(8000, dtype=np.int64), cofp=cofp, nr_bound_part=rng.integers(20, 5000, 8000))
+    chunks = split_halos(halos, 50.0, 8)
+    counts = np.array([len(c["index"]) for c in chunks])
     assert counts.min() == counts.max() == 1000
+    assert np.array_equal(np.sort(np.concatenate([c["index"] for c in chunks])), np.arange(8000))
     # compact: the mean extent of a chunk is well below the box size
-    ext = np.mean([np.ptp(cofp[chunk == k], axis=0).mean() for k in range(8)])
+    ext = np.mean([np.ptp(c["cofp"], axis=0).mean() for c in chunks])
     assert ext < 0.8 * 50.0
+    # inside a chunk: most bound particles first (chunk_tasks.py:118-120)
+    assert all(np.all(np.diff(c["nr_bound_part"]) <= 0) for c in chunks)
