@@ -167,11 +167,11 @@ int32_t soap_engine_destroy(soap_engine *h);
  *   fof            [n]    FOFGroupIDs int64
  *   resolution     mesh cells per dimension (chunk_tasks.py:299-302 computes it)
  *   on_device      0: host pointers, 1: device (HBM) pointers on cfg.device
- * Only the coordinates are physically reordered into cell order; velocities, masses and ids are read in
- * place, through the reorder permutation, for the particles a halo selects.  Lifetime: with
- * on_device == 1 the vel / mass / grnr / fof arrays must stay valid and unchanged until the next
- * soap_engine_stage_particles for this slot or soap_engine_destroy (pos may be reused as soon as this
- * call returns); with on_device == 0 the engine keeps its own device copies.
+ * The call copies everything it needs: the coordinates into cell order (structure of arrays, what the candidate stream of
+ * a halo reads) and velocity, mass, GroupNr_bound, FOF id, coordinates and original index of every particle into one
+ * 80-byte payload record at the particle's cell-ordered position (what the slab build of a halo gathers).  Lifetime: every
+ * input array, host or device, may be reused or freed as soon as the call returns; with on_device == 0 the device copies
+ * made for the mesh build go back to the handle's allocation cache before it returns.
  */
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n,
                                     const double *pos, const double *vel, const double *mass,
@@ -182,8 +182,8 @@ int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n
  * Stage the chunk's neutrino particles (PartType6) and build their mesh.  They enter the spherical-overdensity
  * mass profile with mass * weight (weights may be negative) and feed NumberOfNeutrinoParticles /
  * RawNeutrinoMass / NoiseSuppressedNeutrinoMass and the neutrino terms of the concentration; nothing else
- * sees them (SO_properties.py:380-395, :507-511, :2689-2753).  With on_device == 1 `mass` must stay valid
- * until the next staging call; `weight` is consumed here.  n == 0 removes them.
+ * sees them (SO_properties.py:380-395, :507-511, :2689-2753).  All three arrays are consumed by the call (weighted and raw
+ * masses go into the payload records).  n == 0 removes them.
  */
 int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const double *mass,
                                     const double *weight, int32_t resolution, int32_t on_device);

@@ -461,9 +461,7 @@ __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double 
         double r = sqrt((wx * wx + wy * wy) + wz * wz);
         bool in = strict ? (r < R) : (r <= R);
         if (in && bound_only) {
-            const long long o = T.pay[p].orig;
-            long long g = T.grnr64 ? T.grnr64p[o] : (long long)T.grnr32[o];
-            in = (g == hindex);
+            in = (T.pay[p].grnr == hindex);   // (the payload record: the caller's arrays are not kept after staging)
         }
         if (in) {
             unsigned s = atomicAdd(count, 1u);
@@ -946,22 +944,25 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         // placement + coordinates into cell order
         double **dp[] = {&T.x, &T.y, &T.z};
         for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
-        T.vel = dvel; T.mass = dmass; T.fof = dfof;
-        if (T.grnr64) T.g64 = (const long long *)dgr; else T.g32 = (const int *)dgr;
+        // (velocities, masses and ids are only read by the placement pass below, which copies them into the payload records:
+        // the pointers live in locals, nothing of the caller's -- or of the device copies of host inputs -- is kept)
+        const double *t_vel = dvel, *t_mass = dmass;
+        const long long *t_fof = dfof, *t_g64 = T.grnr64 ? (const long long *)dgr : nullptr;
+        const int *t_g32 = T.grnr64 ? nullptr : (const int *)dgr;
         if (nu) {
             // profile mass = mass * weight (owned array); the raw masses take the place of the velocities
             double *meff;
             HIPCHECK(pool.alloc((void **)&meff, (size_t)n * 8));
-            T.owned.push_back({meff, (size_t)n * 8});
+            scratch.push_back({meff, (size_t)n * 8});
             hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (long long)n, meff);
-            T.vel = dmass;
-            T.mass = meff;
-            T.g32 = nullptr; T.g64 = nullptr; T.fof = nullptr;
+            t_vel = dmass;
+            t_mass = meff;
+            t_g32 = nullptr; t_g64 = nullptr; t_fof = nullptr;
         }
         HIPCHECK(hipEventCreate(&ev2));
         HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
         hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
-                           dpos, T.x, T.y, T.z, T.pay, T.vel, T.mass, T.g32, T.g64, T.fof, nu ? 1 : 0);
+                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_g32, t_g64, t_fof, nu ? 1 : 0);
         HIPCHECK(hipEventRecord(ev2, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -982,11 +983,9 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         T.release(pool);
         return rc;
     }
-    // the coordinate copy goes back to the cache, the other device copies live as long as the mesh
-    if (!inputs.empty()) {
-        pool.release(inputs[0].first, inputs[0].second);
-        for (size_t k = 1; k < inputs.size(); k++) T.owned.push_back(inputs[k]);
-    }
+    // the device copies of host inputs go back to the cache: everything the halo kernels (and the membership probe) read lives
+    // in the cell-ordered coordinates and the payload records
+    for (auto &p : inputs) pool.release(p.first, p.second);
     h->t[ts] = T;
     return 0;
 }
@@ -1085,7 +1084,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (!h) return fail(-1, "null handle");
     TRACE("run: begin");
     if (n_calcs < 1 || n_calcs > MAXCALC)
-        return fail(-2, "number of calculations must be in [1,32]: the per-halo state of every calculation lives in LDS; split a "
+        return fail(-2, "number of calculations must be in [1,64]: one lane of a wavefront and one bit of the done mask each; split a "
                         "longer list into several runs, each starting with the bound subhalo");
     if (!calcs) return fail(-3, "null calcs");
     if (calcs[0].kind != SOAP_CALC_SUBHALO)

@@ -26,7 +26,7 @@
 #define CH 4096            // LDS sort chunk (elements)
 #define PIDX_BITS 29   // packed slab index: 3 bits of type slot, 29 bits of cell-ordered position
 #define PIDX_MASK ((1u << PIDX_BITS) - 1u)
-#define MAXCALC 32
+#define MAXCALC 64   // calculations per run: one lane of a wavefront each in the radius loop, one bit of the 64-bit done mask
 
 // flags byte of a slab element
 #define FL_TYPE 0x7    // type slot 0..3, or NU_SLOT

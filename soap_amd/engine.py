@@ -210,7 +210,7 @@ class Engine:
         return ts[:n].copy(), ix[:n].copy()
 
     # -- run / fetch -------------------------------------------------------------------
-    MAX_CALCULATIONS = 32   # MAXCALC of the kernels: per-calculation state of a halo lives in LDS
+    MAX_CALCULATIONS = 64   # MAXCALC of the kernels: one lane of a wavefront and one bit of the done mask per calculation
 
     def run(self, calcs: Sequence[CalcDesc], target_density):
         if len(calcs) > self.MAX_CALCULATIONS:

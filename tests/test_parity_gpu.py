@@ -437,7 +437,7 @@ def test_chunk_harness_columns_match_per_halo_results(built_library, tmp_path):
 def test_many_calculations_per_family(built_library):
     """More calculations in one family than the engine finalises in one batch (PREFB = 12): the nine default
     SO definitions plus five inclusive spheres = 14 nested selections over all particles, 1 + 5 over the
-    bound ones; 20 calculations in total (the engine limit is 32)."""
+    bound ones; 20 calculations in total."""
     sc, data, halos = make_chunk(90000, 50, seed=29)
     data_np, halos_np = to_numpy(data, halos)
     cf = CategoryFilter(dmo=True)
@@ -450,6 +450,45 @@ def test_many_calculations_per_family(built_library):
     for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
         compare_halo(ref[row], results[j], sc)
     engine.close()
+
+
+@pytest.mark.parametrize("small", ["0", "4"], ids=["thread-group-classes", "small-halo-class"])
+def test_production_sized_calculation_lists(built_library, monkeypatch, small):
+    """The lists the reference's production parameter files build hold 30 (FLAMINGO) and 32 (COLIBRE: 1 + 4 + 18 + 9)
+    calculations (compute_halo_properties.py:232-505); the engine takes up to 64.  A COLIBRE-shaped list of 32 and a list of 45
+    -- thirteen SO definitions, sixteen spheres of each kind -- against the oracle, on the thread-group classes and through the
+    small-halo class."""
+    monkeypatch.setenv("SOAP_ENGINE_SMALL", small)
+    from oracle import halo_oracle as ho
+    from tests.test_small_halo_gpu import _NoInertia
+
+    sc, data, halos = make_chunk(90000, 60, seed=31)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    so13 = {f"{v}_crit": {"value": float(v), "type": "crit"} for v in (50, 100, 200, 300, 500, 750, 1000, 1500, 2500)}
+    so13.update({"200_mean": {"value": 200.0, "type": "mean"}, "BN98": {"value": 0.0, "type": "BN98"},
+                 "3xR_500_crit": {"value": 500.0, "type": "crit", "radius_multiple": 3.0}, "5xR_500_crit": {"value": 500.0, "type": "crit", "radius_multiple": 5.0}})
+    cases = [(dict(list(so13.items())[:4] + [("BN98", so13["BN98"])]), (1.0, 3.0, 5.0, 10.0, 20.0, 30.0, 40.0, 50.0, 60.0, 70.0, 80.0, 100.0, 150.0), 32),
+             (so13, (1.0, 3.0, 5.0, 10.0, 15.0, 20.0, 30.0, 40.0, 50.0, 60.0, 70.0, 80.0, 100.0, 150.0, 300.0, 500.0), 46)]
+    saved = ho.ENABLE_INERTIA
+    ho.ENABLE_INERTIA = False
+    try:
+        for so_vars, radii, want_n in cases:
+            ap_vars = chp.aperture_variations(radii)
+            props = chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, parameters=_NoInertia())
+            assert len(props) == want_n, len(props)
+            engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+            if small != "0":
+                assert engine.kernel_ms("n_small") > 0
+            ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, ap_vars)
+            assert np.array_equal(ha["done"], ha_ref["done"]) and ha["done"].sum() > 10
+            for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
+                compare_halo({k: v for k, v in ref[row].items() if "InertiaTensor" not in k}, results[j], sc)
+            st = out[4]["stats"][out[4]["status"] == 0]
+            assert np.array_equal(st[:, 0], [s["n_loop"] for s in stats]) and np.array_equal(st[:, 1], [s["n_sel"] for s in stats])
+            engine.close()
+    finally:
+        ho.ENABLE_INERTIA = saved
 
 
 def _tiny_periodic_chunk(L=2.0, n=6000, centres=((0.05, 0.1, 1.95), (1.0, 1.0, 1.0)), rb=0.25, seed=0):
