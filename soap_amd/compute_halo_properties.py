@@ -53,6 +53,8 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
                 cellgrid, parameters, None, None, category_filter),
             so=lambda filt, val, typ: SO_properties.SOProperties(
                 cellgrid, parameters, None, category_filter, filt, val, typ),
+            so_core_excised=lambda filt, val, typ, frac: SO_properties.CoreExcisedSOProperties(
+                cellgrid, parameters, None, category_filter, filt, val, typ, core_excision_fraction=frac),
             so_multiple=lambda filt, val, mult, typ: SO_properties.RadiusMultipleSOProperties(
                 cellgrid, parameters, None, category_filter, filt, val, mult, typ),
             inclusive=lambda filt, r, radii: aperture_properties.InclusiveSphereProperties(
@@ -73,7 +75,10 @@ def build_halo_prop_list(cellgrid, category_filter, SO_variations=None, aperture
     for v in SO_variations.values():
         if v.get("radius_multiple", 0.0) > 0.0:
             continue
-        halo_prop_list.append(classes["so"](v.get("filter", "basic"), v["value"], v["type"]))
+        if "core_excision_fraction" in v and "so_core_excised" in classes:   # compute_halo_properties.py:271-285
+            halo_prop_list.append(classes["so_core_excised"](v.get("filter", "basic"), v["value"], v["type"], v["core_excision_fraction"]))
+        else:
+            halo_prop_list.append(classes["so"](v.get("filter", "basic"), v["value"], v["type"]))
     for v in SO_variations.values():
         if v.get("radius_multiple", 0.0) > 0.0:
             halo_prop_list.append(classes["so_multiple"](

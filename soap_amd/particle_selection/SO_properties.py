@@ -1,5 +1,5 @@
 """
-Spherical overdensities: SOProperties and RadiusMultipleSOProperties with the reference's
+Spherical overdensities: SOProperties, CoreExcisedSOProperties and RadiusMultipleSOProperties with the reference's
 constructor signatures, names and density bookkeeping
 (SOAP/particle_selection/SO_properties.py:3215-3567, :3797-3926).
 """
@@ -89,6 +89,21 @@ class SOProperties(HaloProperty):
         if self.virial_definition and self.kind == layout.CALC_SO_DENSITY and "DarkMatterMassFlowRate" in self.enabled_properties():
             d.flags |= layout.CALC_FLAG_DM_FLOW
         return d
+
+
+class CoreExcisedSOProperties(SOProperties):
+    """
+    SOProperties plus the eighteen core-excised temperatures and X-ray luminosities (SO_properties.py:3745-3795): what the
+    reference builds for an SO variation that carries `core_excision_fraction` (compute_halo_properties.py:271-285).  Every
+    one of the extra properties is a sub-grid quantity outside this engine's set, so the
+    class emits exactly what SOProperties emits -- same name, same group, same descriptor -- and a parameter file that lists
+    such a variation goes through `build_halo_prop_list` unchanged.
+    """
+
+    def __init__(self, cellgrid, parameters, recently_heated_gas_filter, category_filter,
+                 halo_filter, SOval, type="mean", core_excision_fraction=None):  # fmt: skip
+        self.core_excision_fraction = core_excision_fraction
+        super().__init__(cellgrid, parameters, recently_heated_gas_filter, category_filter, halo_filter, SOval, type)
 
 
 class RadiusMultipleSOProperties(SOProperties):

@@ -25,6 +25,30 @@ class SearchRadiusTooSmallError(Exception):
     pass
 
 
+_PROPERTY_OF_NAME = {p.name: p for p in full_property_list.values()}
+
+
+def reference_halo_result(halo_result: Dict, unyt, registry=None) -> Dict:
+    """
+    The facade's `halo_result` as the reference's own consumers expect it: every entry the 4-tuple
+    (unyt_array in the table's dtype and unit, description, output_physical, a_scale_exponent) that
+    ResultSet.append takes (SOAP/core/result_set.py:74-130) and that SO_properties.py:3610-3620 builds --
+    unit of the property table, times a**a_scale_exponent when the stored value is comoving.  `unyt` is the
+    unit module of the caller (the reference's process already has it; this package never imports it) and
+    `registry` its snapshot unit registry.
+    """
+    out = {}
+    for name, entry in halo_result.items():
+        stored, description, physical, a_exponent = entry[:4]
+        prop = _PROPERTY_OF_NAME[name.rsplit("/", 1)[-1]]
+        unit = unyt.Unit(prop.unit, registry=registry)
+        if not physical:
+            unit = unit * unyt.Unit("a", registry=registry) ** a_exponent
+        value = stored if prop.shape > 1 else stored.reshape(())
+        out[name] = (unyt.unyt_array(value, dtype=prop.dtype, units=unit, registry=registry), description, physical, a_exponent)
+    return out
+
+
 class HaloProperty:
     # subclasses fill these in, with the same meaning as in the reference
     base_halo_type = "HaloProperty"

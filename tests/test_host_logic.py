@@ -205,3 +205,77 @@ def test_packed_catalogue_equals_the_columns_cut_on_the_host():
         n2, w2 = pk.pack(torch.from_numpy(table))
         assert np.array_equal(n2.numpy(), narrow) and np.array_equal(w2.numpy(), wide)
         assert pk.bytes_per_halo() < 0.6 * 8 * pk.table_columns
+
+
+def test_core_excised_so_variation_builds_the_reference_class():
+    """An SO variation with `core_excision_fraction` becomes a CoreExcisedSOProperties entry
+    (compute_halo_properties.py:271-285); its extra properties are sub-grid ones outside this engine's set, so the
+    entry describes itself to the engine exactly as the plain SOProperties of the same value and type does."""
+    sc = SnapshotScalars()
+    cf = CategoryFilter(dmo=True)
+    plain = {"500_crit": {"value": 500.0, "type": "crit"}}
+    excised = {"500_crit": {"value": 500.0, "type": "crit", "core_excision_fraction": 0.15}}
+    pa = chp.build_halo_prop_list(sc, cf, plain, chp.aperture_variations((50.0,)))
+    pb = chp.build_halo_prop_list(sc, cf, excised, chp.aperture_variations((50.0,)))
+    assert type(pb[1]) is SO_properties.CoreExcisedSOProperties and type(pa[1]) is SO_properties.SOProperties
+    assert isinstance(pb[1], SO_properties.SOProperties) and pb[1].core_excision_fraction == 0.15
+    assert [p.name for p in pa] == [p.name for p in pb] and [p.group_name for p in pa] == [p.group_name for p in pb]
+    assert pb[1].enabled_properties() == pa[1].enabled_properties()
+    da, db = pa[1].calc_desc(pa, 1), pb[1].calc_desc(pb, 1)
+    assert bytes(da) == bytes(db)
+    assert halo_tasks.target_density_of(pa, sc) == halo_tasks.target_density_of(pb, sc)
+
+
+def test_halo_result_wraps_into_the_tuples_result_set_append_takes():
+    """reference_halo_result: every entry of the facade's halo_result as the 4-tuple ResultSet.append consumes
+    (SOAP/core/result_set.py:74-130): a unit-carrying array in the table's dtype and unit (x a**exponent when the stored
+    value is comoving), then description, physical flag, exponent.  The unit module here is the unit-aware stand-in the
+    golden vectors were made with (tests/golden/_shims_units); the checks are the ones append makes."""
+    import importlib.util
+    import os
+    import sys
+
+    from soap_amd.particle_selection.halo_properties import reference_halo_result
+
+    here = os.path.join(os.path.dirname(__file__), "golden", "_shims_units", "unyt", "__init__.py")
+    spec = importlib.util.spec_from_file_location("_units_standin", here)
+    unyt = importlib.util.module_from_spec(spec)
+    sys.modules["_units_standin"] = unyt
+    spec.loader.exec_module(unyt)
+    a = 0.769
+    unyt.define_golden_system(a, 1.0e-3, 43.0)
+
+    sc = SnapshotScalars(a=a)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}}, chp.aperture_variations((50.0,)))
+    rng = np.random.default_rng(11)
+    ncols = [int(layout.desc_columns(hp.calc_desc(props, i))) for i, hp in enumerate(props)]
+    results = []
+    for halo in range(3):
+        halo_result = {}
+        for hp, nc in zip(props, ncols):
+            hp.unpack(rng.uniform(1.0, 2.0, size=nc), halo_result, None)
+        results.append(reference_halo_result(halo_result, unyt, registry=None))
+
+    # what ResultSet.append does with them (result_set.py:96-130)
+    arrays = {}
+    for i, res in enumerate(results):
+        for name, (data, description, physical, a_exponent) in res.items():
+            assert hasattr(data, "units") and isinstance(description, str)
+            if name not in arrays:
+                arr = np.empty_like(unyt.unyt_array(data, registry=data.units.registry), shape=(len(results),) + data.shape)
+                arrays[name] = [arr, description, physical, a_exponent]
+            arr = arrays[name][0]
+            assert data.units == arr.units and data.dtype == arr.dtype and data.shape == arr.shape[1:], name
+            arr[i, ...] = data
+    r = arrays["SO/200_crit/SORadius"]
+    assert r[0].dtype == np.float32 and r[0].shape == (3,) and r[2] is False and r[3] == 1
+    assert r[0].units == unyt.Unit("snap_length") * unyt.Unit("a") ** 1
+    # comoving -> physical is a factor a, as in the reference's registry
+    assert np.allclose(np.asarray(r[0].to("snap_length")), np.asarray(r[0]) * a, rtol=1e-6)
+    com = arrays["BoundSubhalo/CentreOfMass"]
+    assert com[0].dtype == np.float64 and com[0].shape == (3, 3)
+    n = arrays["BoundSubhalo/NumberOfDarkMatterParticles"]
+    assert n[0].dtype == np.uint32 and n[0].units == unyt.Unit("dimensionless") and n[2] is True
+    m = arrays["SO/200_crit/TotalMass"]
+    assert m[0].units == unyt.Unit("snap_mass") and m[2] is True
