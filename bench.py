@@ -74,8 +74,11 @@ class _NamedPropertySet:
     radii, v_max, concentration, flow rates); the inertia tensors (up to 20 passes per tensor over
     the search sphere) are switched off, for the engine and for the CPU baseline alike."""
 
+    def __init__(self, inertia=False):
+        self.inertia = inertia or os.environ.get("BENCH_INERTIA") == "1"   # (the environment switch: a diagnostic)
+
     def get_property_filters(self, base_halo_type, names):
-        if os.environ.get("BENCH_INERTIA") == "1":   # diagnostic: the same configurations with the tensors on
+        if self.inertia:   # the same configurations with the tensors on (the `full_set` block of the JSON line)
             return {n: "basic" for n in names}
         return {n: (False if "InertiaTensor" in n else "basic") for n in names}
 
@@ -83,7 +86,7 @@ class _NamedPropertySet:
         return False
 
 
-def build_props(sc, wl):
+def build_props(sc, wl, inertia=False):
     from soap_amd import compute_halo_properties as chp
     from soap_amd.core.category_filter import CategoryFilter
 
@@ -92,7 +95,7 @@ def build_props(sc, wl):
     ap_vars = chp.aperture_variations(wl["apertures"]) if wl["apertures"] else {}
     pj_vars = chp.projected_variations(wl["projected"]) if wl.get("projected") else {}
     return cf, so_vars, ap_vars, pj_vars, chp.build_halo_prop_list(sc, cf, so_vars, ap_vars, projected_vars=pj_vars,
-                                                                   parameters=_NamedPropertySet())
+                                                                   parameters=_NamedPropertySet(inertia))
 
 
 # ---- CPU baseline: the oracle on the host cores ------------------------------------------------------------
@@ -144,21 +147,15 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
-    """Oracle (CPU restatement of the reference) timed on a bounded sample of the SAME box: the halos whose
-    read sphere lies inside a sub-cube, with the particles of that sub-cube copied to the host.  Only
-    process_halos-equivalent work is timed: first on one core, then with one worker per core of this
-    process' CPU share pulling halos from a shared counter (BASELINE.md section 3)."""
-    import multiprocessing as mp
-
+def subcube_sample(sc, data, halos, target_particles=3.0e6):
+    """A bounded sample of a box for the CPU oracle: the halos whose read sphere lies inside the sub-cube [0, f L]^3 that holds
+    about `target_particles` particles, and the particles of that sub-cube on the host (in their staged order, so that ties of
+    the (r, index) sort fall the same way).  Returns (rows of the halo table, particle arrays, halo arrays, f) or None."""
     import torch
-
-    from oracle import halo_oracle as ho
-    from tests import helpers
 
     L = sc.boxsize
     n = sum(int(d["Coordinates"].shape[0]) for d in data.values())
-    frac = min(1.0, (3.0e6 / n) ** (1.0 / 3.0))   # about 3e6 particles on the host
+    frac = min(1.0, (target_particles / n) ** (1.0 / 3.0))
     side = L * frac
     rr = halos["read_radius"]
     c = halos["cofp"]
@@ -171,6 +168,25 @@ def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
         psel = (d["Coordinates"] <= side).all(dim=1)
         d_np[pt] = {k: v[psel].cpu().numpy() for k, v in d.items()}
     h_np = {k: v[rows].cpu().numpy() for k, v in halos.items()}
+    return rows.cpu().numpy(), d_np, h_np, frac
+
+
+def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
+    """Oracle (CPU restatement of the reference) timed on a bounded sample of the SAME box: the halos whose
+    read sphere lies inside a sub-cube, with the particles of that sub-cube copied to the host.  Only
+    process_halos-equivalent work is timed: first on one core, then with one worker per core of this
+    process' CPU share pulling halos from a shared counter (BASELINE.md section 3)."""
+    import multiprocessing as mp
+
+    import torch
+
+    from oracle import halo_oracle as ho
+    from tests import helpers
+
+    sample = subcube_sample(sc, data, halos)
+    if sample is None:
+        return None
+    rows, d_np, h_np, frac = sample
     order = np.argsort(h_np["nr_bound_part"])[::-1]
     h_np = {k: v[order] for k, v in h_np.items()}
     cf, so_vars, ap_vars, pj_vars, _ = build_props(sc, wl)
@@ -241,6 +257,7 @@ def main():
     ap.add_argument("--passes-per-step", type=int, default=8)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-set", action="store_true", help="skip the full_set block (tensors on, halo size cap lifted)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
 
@@ -284,119 +301,164 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     cf, so_vars, ap_vars, pj_vars, props = build_props(sc, wl)
-    A = len(props)
-    halos_all = {k: v.cpu().numpy() for k, v in halos.items()}
-    snapshot = chunk_tasks.SnapshotCells(data, sc.boxsize, (TOPCELLS,) * 3)
-    n_box = snapshot.nr_particles()
-    if world > 1:
-        halos_np = chunk_tasks.split_halos(halos_all, sc.boxsize, world)[rank]
-        region, _, mask0 = chunk_tasks.read_chunk(snapshot, halos_np, wrap=True, return_mask=True)
-        # how far the cells this rank read are complete around each of its halos: read-radius updates that stay
-        # inside need no re-read (soap_engine_set_resident_radius)
-        resident0 = chunk_tasks.resident_radius(mask0, snapshot.cell_size, halos_np["cofp"], halos_np["read_radius"])
-        torch.cuda.synchronize()
-    else:
-        halos_np = halos_all
-        region = data
-        resident0 = np.full(len(halos_np["index"]), np.inf)   # the whole periodic box is resident
-    H = len(halos_np["index"])
-    n_region = sum(int(d["Coordinates"].shape[0]) for d in region.values())
-    cell_size = snapshot.cell_size
-    d_cofp = torch.as_tensor(halos_np["cofp"], device=dev)
-    d_index = torch.as_tensor(halos_np["index"], device=dev)
 
-    engine = halo_tasks.make_engine(sc, device=local_rank)
-    state = dict(nleft=0, npass=0, ncols=None, raw=None, catalogue=None, table=None)
-    packed = PackedLayout(props, engine.desc_columns)
-    ms_halo, ms_mesh, ms_reorder = [], [], []
-
-    def one_pass(record):
-        """ChunkTask loop for the resident region: stage, process, and again for the halos that need a larger
-        read radius (their cells are read again, chunk_tasks.py:189-367)."""
-        ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
-        cur, resident = region, resident0
-        stats = status = None
-        table = state["table"]
-        t_h = 0.0
-        for it in range(8):
-            halo_tasks.stage_chunk(engine, cur)
-            if it == 0 and record:
-                ms_mesh.append(engine.kernel_ms("mesh"))
-                ms_reorder.append(engine.kernel_ms("reorder"))
-            out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False, resident_radius=resident)
-            raw = out[4]
-            t_h += engine.kernel_ms("halo")
-            rows = raw["rows"]
-            okm = raw["status"] == 0
-            if stats is None and rows.size == H and okm.all():
-                stats, status = raw["stats"], raw["status"]   # every halo finished in the first call: the engine's arrays as they are
-            else:
-                if stats is None:
-                    stats = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
-                    status = np.full(H, -99, dtype=np.int32)
-                stats[rows[okm]] = raw["stats"][okm]
-                status[rows] = raw["status"]
-            if table is None:
-                state["ncols"] = engine.row_columns
-                table = state["table"] = torch.zeros((H, state["ncols"]), dtype=torch.float64, device=dev)
-            # finished rows into this pass' catalogue table (device to device)
-            if rows.size == H:
-                engine.copy_table_to(table.view(-1))
-            else:
-                part = torch.empty((rows.size, state["ncols"]), dtype=torch.float64, device=dev)
-                engine.copy_table_to(part.view(-1))
-                sel = torch.as_tensor(rows[okm], device=dev)
-                table[sel] = part[torch.as_tensor(np.flatnonzero(okm), device=dev)]
-            state["npass"] += 1
-            if out[2] == 0:
-                break
-            cur, _, mk = chunk_tasks.read_chunk(snapshot, ha, wrap=world > 1, return_mask=True)
-            resident = chunk_tasks.resident_radius(mk, snapshot.cell_size, ha["cofp"], ha["read_radius"])
-        if record:
-            ms_halo.append(t_h)
-        state["nleft"] = int(np.sum(ha["done"] == 0))
-        if state["nleft"]:   # (the chunk loop of the reference runs until no halo is left: a pass that leaves some is not a measurement)
-            raise RuntimeError(f"{state['nleft']} halos unfinished after 8 read-radius iterations")
-        state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
-                            radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
-        # final catalogue: concatenation over the ranks in (cell, catalogue index) order
-        narrow, wide = packed.pack(table)
-        state["catalogue"] = gather_catalogue_packed(narrow, wide, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
-
-    def sync():
+    def measure(wl, sc, data, halos, props, n_steps, n_warmup):
+        """n_warmup untimed and n_steps timed steps of passes_per_step passes over one box with one calculation list; returns the
+        locals the JSON line is made of (the engine of the measurement still open: the caller reads its clocks and closes it)"""
+        A = len(props)
+        halos_all = {k: v.cpu().numpy() for k, v in halos.items()}
+        snapshot = chunk_tasks.SnapshotCells(data, sc.boxsize, (TOPCELLS,) * 3)
+        n_box = snapshot.nr_particles()
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            halos_np = chunk_tasks.split_halos(halos_all, sc.boxsize, world)[rank]
+            region, _, mask0 = chunk_tasks.read_chunk(snapshot, halos_np, wrap=True, return_mask=True)
+            # how far the cells this rank read are complete around each of its halos: read-radius updates that stay
+            # inside need no re-read (soap_engine_set_resident_radius)
+            resident0 = chunk_tasks.resident_radius(mask0, snapshot.cell_size, halos_np["cofp"], halos_np["read_radius"])
+            torch.cuda.synchronize()
+        else:
+            halos_np = halos_all
+            region = data
+            resident0 = np.full(len(halos_np["index"]), np.inf)   # the whole periodic box is resident
+        H = len(halos_np["index"])
+        n_region = sum(int(d["Coordinates"].shape[0]) for d in region.values())
+        cell_size = snapshot.cell_size
+        d_cofp = torch.as_tensor(halos_np["cofp"], device=dev)
+        d_index = torch.as_tensor(halos_np["index"], device=dev)
 
-    one_pass(False)   # engine set-up: memory pools, slabs and torch's allocator reach their working size (never timed)
-    for _ in range(args.warmup):   # a warm-up STEP is what a timed step is: passes_per_step passes
-        for _ in range(args.passes_per_step):
-            one_pass(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for _ in range(args.passes_per_step):
-            one_pass(True)
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    npasses = args.steps * args.passes_per_step
+        engine = halo_tasks.make_engine(sc, device=local_rank)
+        state = dict(nleft=0, npass=0, ncols=None, raw=None, catalogue=None, table=None)
+        packed = PackedLayout(props, engine.desc_columns)
+        ms_halo, ms_mesh, ms_reorder = [], [], []
 
-    raw = state["raw"]
-    stats = raw["stats"]
-    ok = raw["status"] == 0
-    n_sel = int(stats[ok, 1].sum())
-    n_cand = int(stats[ok, 2].sum())
-    evals = n_sel * A
-    tot = torch.tensor([evals, int(ok.sum()), n_cand, n_region, state["nleft"]], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    evals_all, halos_all_ok, ncand_all, nregion_all, nleft_all = (float(x) for x in tot.tolist())
-    cat_table = state["catalogue"][0]
-    assert cat_table.shape[0] == wl["n_halo"], (cat_table.shape, wl["n_halo"])
+        def one_pass(record):
+            """ChunkTask loop for the resident region: stage, process, and again for the halos that need a larger
+            read radius (their cells are read again, chunk_tasks.py:189-367)."""
+            ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
+            cur, resident = region, resident0
+            stats = status = None
+            table = state["table"]
+            t_h = 0.0
+            for it in range(8):
+                halo_tasks.stage_chunk(engine, cur)
+                if it == 0 and record:
+                    ms_mesh.append(engine.kernel_ms("mesh"))
+                    ms_reorder.append(engine.kernel_ms("reorder"))
+                out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False, resident_radius=resident)
+                raw = out[4]
+                t_h += engine.kernel_ms("halo")
+                rows = raw["rows"]
+                okm = raw["status"] == 0
+                if stats is None and rows.size == H and okm.all():
+                    stats, status = raw["stats"], raw["status"]   # every halo finished in the first call: the engine's arrays as they are
+                else:
+                    if stats is None:
+                        stats = np.zeros((H, layout.STATS_COLUMNS), dtype=np.int64)
+                        status = np.full(H, -99, dtype=np.int32)
+                    stats[rows[okm]] = raw["stats"][okm]
+                    status[rows] = raw["status"]
+                if table is None:
+                    state["ncols"] = engine.row_columns
+                    table = state["table"] = torch.zeros((H, state["ncols"]), dtype=torch.float64, device=dev)
+                # finished rows into this pass' catalogue table (device to device)
+                if rows.size == H:
+                    engine.copy_table_to(table.view(-1))
+                else:
+                    part = torch.empty((rows.size, state["ncols"]), dtype=torch.float64, device=dev)
+                    engine.copy_table_to(part.view(-1))
+                    sel = torch.as_tensor(rows[okm], device=dev)
+                    table[sel] = part[torch.as_tensor(np.flatnonzero(okm), device=dev)]
+                state["npass"] += 1
+                if out[2] == 0:
+                    break
+                cur, _, mk = chunk_tasks.read_chunk(snapshot, ha, wrap=world > 1, return_mask=True)
+                resident = chunk_tasks.resident_radius(mk, snapshot.cell_size, ha["cofp"], ha["read_radius"])
+            if record:
+                ms_halo.append(t_h)
+            state["nleft"] = int(np.sum(ha["done"] == 0))
+            if state["nleft"]:   # (the chunk loop of the reference runs until no halo is left: a pass that leaves some is not a measurement)
+                raise RuntimeError(f"{state['nleft']} halos unfinished after 8 read-radius iterations")
+            state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
+                                radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
+            # final catalogue: concatenation over the ranks in (cell, catalogue index) order
+            narrow, wide = packed.pack(table)
+            state["catalogue"] = gather_catalogue_packed(narrow, wide, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
+
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        one_pass(False)   # engine set-up: memory pools, slabs and torch's allocator reach their working size (never timed)
+        for _ in range(n_warmup):   # a warm-up STEP is what a timed step is: passes_per_step passes
+            for _ in range(args.passes_per_step):
+                one_pass(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            for _ in range(args.passes_per_step):
+                one_pass(True)
+        sync()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        npasses = n_steps * args.passes_per_step
+
+        raw = state["raw"]
+        stats = raw["stats"]
+        ok = raw["status"] == 0
+        n_sel = int(stats[ok, 1].sum())
+        n_cand = int(stats[ok, 2].sum())
+        evals = n_sel * A
+        tot = torch.tensor([evals, int(ok.sum()), n_cand, n_region, state["nleft"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        evals_all, halos_all_ok, ncand_all, nregion_all, nleft_all = (float(x) for x in tot.tolist())
+        cat_table = state["catalogue"][0]
+        assert cat_table.shape[0] == wl["n_halo"], (cat_table.shape, wl["n_halo"])
+
+        return dict(locals())
+
+    M = measure(wl, sc, data, halos, props, args.steps, args.warmup)
+    (engine, packed, state, raw, stats, ok, n_sel, n_cand, A, H, dt, npasses, n_region, n_box, evals_all, halos_all_ok, nregion_all,
+     nleft_all, ms_halo, ms_mesh, ms_reorder) = (M[k] for k in (
+        "engine", "packed", "state", "raw", "stats", "ok", "n_sel", "n_cand", "A", "H", "dt", "npasses", "n_region", "n_box", "evals_all",
+        "halos_all_ok", "nregion_all", "nleft_all", "ms_halo", "ms_mesh", "ms_reorder"))
+
+    def halo_counts(engine):
+        return {
+            "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single"))},
+            "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
+            "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
+                                int(engine.kernel_ms("n_wg1024"))],
+            # the small-halo class (one wavefront per halo, slab in LDS): halos that went through its 128- / 512-entry kernels, and
+            # how many of them were handed on to the wavefront class (counted there too)
+            "halos_small_class": {"slab128": int(engine.kernel_ms("n_small128")), "slab512": int(engine.kernel_ms("n_small512")),
+                                  "handed_on": int(engine.kernel_ms("n_small_escalated"))},
+        }  # fmt: skip
+
+    def variant_block(name, wl_v, sc_v, data_v, halos_v, inertia):
+        """one entry of `full_set`: the same measurement (same passes, same catalogue gather) with another calculation list or box"""
+        props_v = build_props(sc_v, wl_v, inertia=inertia)[4]
+        V = measure(wl_v, sc_v, data_v, halos_v, props_v, 1, 0)
+        eng = V["engine"]
+        t_halo = float(np.mean(V["ms_halo"])) * 1e-3
+        b_alg = V["n_cand"] * B_PARTICLE + V["H"] * eng.row_columns * 8
+        blk = {
+            "workload": name, "calculations": V["A"], "row_columns": int(eng.row_columns), "passes": V["npasses"],
+            "value": V["evals_all"] * V["npasses"] / V["dt"], "unit": "evals/s",
+            "ms_per_pass": V["dt"] / V["npasses"] * 1e3,
+            "halos_unfinished": int(V["nleft_all"]),
+            "kernel_ms": {"halo": float(np.mean(V["ms_halo"])), "mesh": float(np.mean(V["ms_mesh"])), "reorder": float(np.mean(V["ms_reorder"]))},
+            "roofline": {"bound": "hbm", "achieved": b_alg / t_halo / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_alg / t_halo / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b_alg, "traffic": None},
+            "n_sel_max": int(V["stats"][V["ok"], 1].max()), "n_sel_sum": V["n_sel"], "n_cand_sum": V["n_cand"],
+            **halo_counts(eng),
+        }  # fmt: skip
+        eng.close()
+        return blk
 
     if rank == 0:
         ncols = engine.row_columns
@@ -452,14 +514,7 @@ def main():
                           "pipe_stage_b": engine.kernel_ms("pipe_stage_b"),
                           "pipe_build_by_class": [engine.kernel_ms("pipe_build_" + c) for c in ("wave", "wg256", "wg1024")],
                           "pipe_props_by_class": [engine.kernel_ms("pipe_props_" + c) for c in ("wave", "wg256", "wg1024")]},
-            "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single"))},
-            "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
-            "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
-                                int(engine.kernel_ms("n_wg1024"))],
-            # the small-halo class (one wavefront per halo, slab in LDS): halos that went through its 128- / 512-entry kernels, and
-            # how many of them were handed on to the wavefront class (counted there too)
-            "halos_small_class": {"slab128": int(engine.kernel_ms("n_small128")), "slab512": int(engine.kernel_ms("n_small512")),
-                                  "handed_on": int(engine.kernel_ms("n_small_escalated"))},
+            **halo_counts(engine),
             **({"phase_cycles": engine.phase_cycles()} if os.environ.get("SOAP_ENGINE_PROFILE") == "1" else {}),   # diagnostics
             "roofline": {
                 "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -479,6 +534,26 @@ def main():
             "n_loop_mean": float(stats[ok, 0].mean()), "n_sel_max": int(stats[ok, 1].max()),
             "n_sel_sum": n_sel, "n_cand_sum": n_cand,
         }  # fmt: skip
+        engine.close()
+        engine = None
+        M.clear()
+        if world == 1 and not args.no_full_set and args.workload == "c3":
+            # BASELINE.json's "full" property set and catalogue shape, measured in this process after the headline configuration:
+            # the inertia tensors on (property_calculation/inertia_tensors.py:19-132, up to 20 passes per tensor), the halo size cap of
+            # the synthetic catalogue lifted to 1e6 particles (the giants go through the multi-workgroup pipeline), and both
+            try:
+                full = {"note": "same process, same pass as the headline line (stage, halo kernels, catalogue gather), 1 untimed "
+                                "set-up pass + 1 step of passes_per_step passes each"}
+                full["inertia_on"] = variant_block(wl["name"].replace("inertia tensors off", "inertia tensors ON"), wl, sc, data, halos, True)
+                wl_u = dict(wl, max_halo=1_000_000, name=wl["name"].replace("capped at 3e5", "capped at 1e6"))
+                sc_u, data_u, halos_u = make_chunk(wl_u["n_part"], wl_u["n_halo"], seed=args.seed, device=dev, max_halo=wl_u["max_halo"])
+                full["uncapped"] = variant_block(wl_u["name"], wl_u, sc_u, data_u, halos_u, False)
+                full["uncapped_inertia_on"] = variant_block(wl_u["name"].replace("inertia tensors off", "inertia tensors ON"),
+                                                            wl_u, sc_u, data_u, halos_u, True)
+                del data_u, halos_u
+                line["full_set"] = full
+            except Exception as e:   # never hide the headline number
+                line["full_set"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(sc, data, halos, wl)
@@ -487,7 +562,8 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    engine.close()
+    if engine is not None:
+        engine.close()
     if world > 1:
         dist.destroy_process_group()
 

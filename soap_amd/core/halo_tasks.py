@@ -143,6 +143,20 @@ def bind_results(engine: Engine, halo_prop_list: List, raw: Dict, halo_arrays: D
     return batch
 
 
+def unpack_row(halo_prop_list: List, coloff, row) -> Dict:
+    """One row of the engine's result table as the reference's `halo_result` (every calculation's `unpack` in list order;
+    `coloff`: first column of each calculation's block)."""
+    halo_result = {}
+    do_calc = None
+    for ci, hp in enumerate(halo_prop_list):
+        hp.unpack(row[coloff[ci] : coloff[ci + 1]], halo_result, do_calc)
+        if ci == 0 and getattr(hp, "category_filter", None) is not None:
+            # property-level filters use the bound subhalo's particle counts
+            # (subhalo_properties.py:2618-2626)
+            do_calc = hp.category_filter.get_do_calculation(halo_result)
+    return halo_result
+
+
 def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: Dict, results,
                   unpack: bool = True, resident_radius=None):  # fmt: skip
     """
@@ -207,15 +221,7 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
         coloff = np.concatenate([[0], np.cumsum([engine.desc_columns(c) for c in calcs])])
         table = out["table"]
         for j in np.flatnonzero(ok):
-            row = table[j]
-            halo_result = {}
-            do_calc = None
-            for ci, hp in enumerate(halo_prop_list):
-                hp.unpack(row[coloff[ci] : coloff[ci + 1]], halo_result, do_calc)
-                if ci == 0 and getattr(hp, "category_filter", None) is not None:
-                    # property-level filters use the bound subhalo's particle counts
-                    # (subhalo_properties.py:2618-2626)
-                    do_calc = hp.category_filter.get_do_calculation(halo_result)
+            halo_result = unpack_row(halo_prop_list, coloff, table[j])
             i = todo[j]
             for name, (dset, dtype, desc, phys, aexp) in _INPUT_HALO_COLUMNS.items():
                 halo_result[dset] = (np.asarray(halo_arrays[name][i]).astype(dtype), desc, phys, aexp)
