@@ -47,7 +47,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 B_PARTICLE = 68  # x,y,z,vx,vy,vz,m fp64 + GroupNr_bound i32 + FOFGroupIDs i64
-TOPCELLS = 16    # top-level cells per dimension of the synthetic snapshot (soap_amd/synthetic.py)
+# top-level cells per dimension of the synthetic snapshot (soap_amd/synthetic.py; SWIFT boxes of this size are written with 32-64).
+# A chunk reads whole cells half a cell beyond its halos' read spheres (mask_cells.py:30-34), so the grid sets how many
+# particles the ranks of a multi-GPU run hold twice
+TOPCELLS = int(os.environ.get("BENCH_TOPCELLS", "32"))
+# how `--gpus N` cuts the Peano-Hilbert curve into ranks: "work" = equal estimated work (domain_decomposition.halo_work_weights),
+# "count" = the reference's equal halo count (domain_decomposition.py:135-140)
+RANK_CUT = os.environ.get("BENCH_RANK_CUT", "count")
 
 WORKLOADS = {
     "c3": dict(n_part=100_000_000, n_halo=100_000, so="default", apertures=(30.0, 50.0, 100.0),
@@ -297,7 +303,7 @@ def main():
     t_gen = time.time()
     # every rank builds the SAME box (same seed) and keeps its chunk's region of it
     sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed, device=dev, hydro=wl.get("hydro", False),
-                                 max_halo=wl.get("max_halo"))
+                                 max_halo=wl.get("max_halo"), topcells=TOPCELLS)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     cf, so_vars, ap_vars, pj_vars, props = build_props(sc, wl)
@@ -310,7 +316,7 @@ def main():
         snapshot = chunk_tasks.SnapshotCells(data, sc.boxsize, (TOPCELLS,) * 3)
         n_box = snapshot.nr_particles()
         if world > 1:
-            halos_np = chunk_tasks.split_halos(halos_all, sc.boxsize, world)[rank]
+            halos_np = chunk_tasks.split_halos(halos_all, sc.boxsize, world, weights="work" if RANK_CUT == "work" else None)[rank]
             region, _, mask0 = chunk_tasks.read_chunk(snapshot, halos_np, wrap=True, return_mask=True)
             # how far the cells this rank read are complete around each of its halos: read-radius updates that stay
             # inside need no re-read (soap_engine_set_resident_radius)
@@ -469,7 +475,7 @@ def main():
         # bench): only quoted when the workload is the one that was profiled
         traffic = None
         tnote = "no PMC profile of this workload committed"
-        for prof in ("round2", "round1"):
+        for prof in ("round3", "round2", "round1"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof, "final_c3_hbm_traffic.json")) as f:
                     pj = json.load(f)
@@ -498,7 +504,7 @@ def main():
             "config": {"workload": wl["name"], "workload_key": args.workload, "particles": wl["n_part"],
                        "halos": wl["n_halo"], "calculations": A, "seed": args.seed,
                        "passes_per_step": args.passes_per_step,
-                       "chunks": world, "mesh_resolution": int(halo_tasks.mesh_resolution(n_region))},
+                       "chunks": world, "top_level_cells": TOPCELLS, "rank_cut": RANK_CUT if world > 1 else None, "mesh_resolution": int(halo_tasks.mesh_resolution(n_region))},
             "ms_per_pass": dt / npasses * 1e3,
             "halos_per_s": halos_all_ok * npasses / dt,
             "halos_unfinished": int(nleft_all),
@@ -517,7 +523,7 @@ def main():
             **halo_counts(engine),
             **({"phase_cycles": engine.phase_cycles()} if os.environ.get("SOAP_ENGINE_PROFILE") == "1" else {}),   # diagnostics
             "roofline": {
-                "bound": "hbm", "kernel": "k_halo", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_halo + k_small (the concurrent launches of the halo phase)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes": b_alg,
                 "note": "rank 0, per pass: sum_h n_cand(h)*68 B + H*P*8 B / HIP-event duration of the halo kernels of all "
@@ -546,7 +552,8 @@ def main():
                                 "set-up pass + 1 step of passes_per_step passes each"}
                 full["inertia_on"] = variant_block(wl["name"].replace("inertia tensors off", "inertia tensors ON"), wl, sc, data, halos, True)
                 wl_u = dict(wl, max_halo=1_000_000, name=wl["name"].replace("capped at 3e5", "capped at 1e6"))
-                sc_u, data_u, halos_u = make_chunk(wl_u["n_part"], wl_u["n_halo"], seed=args.seed, device=dev, max_halo=wl_u["max_halo"])
+                sc_u, data_u, halos_u = make_chunk(wl_u["n_part"], wl_u["n_halo"], seed=args.seed, device=dev, max_halo=wl_u["max_halo"],
+                                                           topcells=TOPCELLS)
                 full["uncapped"] = variant_block(wl_u["name"], wl_u, sc_u, data_u, halos_u, False)
                 full["uncapped_inertia_on"] = variant_block(wl_u["name"].replace("inertia tensors off", "inertia tensors ON"),
                                                             wl_u, sc_u, data_u, halos_u, True)

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-prof_final}
 mkdir -p $OUT
 cd $R
-CMD="python3 bench.py --workload c3 --steps 1 --warmup 0 --passes-per-step 4 --no-cpu-baseline"
+CMD="python3 bench.py --workload c3 --steps 1 --warmup 0 --passes-per-step 4 --no-cpu-baseline --no-full-set"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- $CMD > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > $OUT/write.log 2>&1 || exit 1

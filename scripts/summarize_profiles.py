@@ -16,7 +16,9 @@ shutil.copy(stats, f"{DST}/{TAG}_c3_kernel_stats_all_launches.csv")   # rocprofv
 
 
 def step_launches(values):
-    """bench.py brings the catalogue radii to their steady state before the timed region: one full pass and a
+    """(the cleanup launch of the wavefront class -- the halos the small-halo class hands on -- is a launch of its own, shorter
+    than the class' main launch: it is counted with the short ones, its bytes are small.)
+    bench.py brings the catalogue radii to their steady state before the timed region: one full pass and a
     few passes over the ~35 halos that asked for a larger read radius.  Those short launches of the same
     kernels are not steps: keep the launches within a factor two of the largest one."""
     top = max(values)
@@ -25,11 +27,18 @@ def step_launches(values):
 
 # per-kernel durations of the step launches, from the kernel trace of the same run
 trace = newest(f"{SRC}/stats/*/*kernel_trace.csv")
+def is_halo(name):
+    """the kernels of the halo phase: the thread-group classes and the small-halo class"""
+    return "k_halo" in name or "k_small" in name
+
+
 def kname(row, wg_key):
     """the three thread-group classes are one kernel name compiled three times: tell them apart by the workgroup size"""
     name = row["Kernel_Name"]
     if "k_halo" in name:
         return f"k_halo<{row[wg_key]} threads per halo>"
+    if "k_small" in name:
+        return name[name.index("k_small"):].split("(")[0]
     return name
 
 
@@ -46,20 +55,20 @@ with open(f"{DST}/{TAG}_c3_kernel_stats.csv", "w", newline="") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "ShortLaunchesExcluded"])
     for r in sorted(rows, key=lambda r: -r[2]):
         w.writerow([r[0], r[1], r[2], r[3], round(100.0 * r[2] / tot, 4), r[4], r[5], r[6]])
-dur = {r[0]: r[3] * 1e-6 for r in rows if "k_halo" in r[0]}
+dur = {r[0]: r[3] * 1e-6 for r in rows if is_halo(r[0])}
 
 def pmc(name, counter):
     f = newest(f"{SRC}/{name}/*/*counter_collection.csv")
     vals = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == counter and "k_halo" in row["Kernel_Name"]:
+        if row["Counter_Name"] == counter and is_halo(row["Kernel_Name"]):
             vals[kname(row, "Workgroup_Size")].append(float(row["Counter_Value"]))
     return {k: sum(step_launches(v)) / len(step_launches(v)) for k, v in vals.items()}
 
 fetch_kb, write_kb = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 line = json.loads(open(f"{SRC}/bench_c3.json").read().strip().splitlines()[-1])
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --workload c3 --steps 1 --warmup 0 --passes-per-step 4 --no-cpu-baseline (scripts/collect_profiles.sh; one counter per run)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --workload c3 --steps 1 --warmup 0 --passes-per-step 4 --no-cpu-baseline --no-full-set (scripts/collect_profiles.sh; one counter per run)",
     "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB per launch (rocprofv3 derived counters).  MI355X_MICROARCH.md: on gfx950 "
                  "FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled ('corrected'); the factor is calibrated "
                  "for 16 B/lane streaming reads, our loads are 8 B/lane and partly gathers, so raw and corrected bracket the truth.",
@@ -84,7 +93,7 @@ for d in sorted(glob.glob(f"{SRC}/sq*/")):
         continue
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
-        if "k_halo" in row["Kernel_Name"]:
+        if is_halo(row["Kernel_Name"]):
             vals[kname(row, "Workgroup_Size")][row["Counter_Name"]].append(
                 (float(row["Counter_Value"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), int(row["VGPR_Count"]),
                  int(row["Accum_VGPR_Count"]), int(row["SGPR_Count"]), int(row["Scratch_Size"]), int(row["LDS_Block_Size"]),
@@ -114,7 +123,7 @@ if sq:
             d["instruction_mix"] = {n: v / sum(insts.values()) for n, v in insts.items()}
         e["derived"] = d
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --workload c3 --steps 1 --warmup 0 --passes-per-step 4 "
-                          "--no-cpu-baseline (scripts/collect_profiles.sh; one counter group per run; the three classes of k_halo run "
+                          "--no-cpu-baseline --no-full-set (scripts/collect_profiles.sh; one counter group per run; the three classes of k_halo run "
                           "concurrently, counters are per dispatch, averaged over the full-size launches)",
                "per_kernel": sq}, open(f"{DST}/{TAG}_c3_sq_counters.json", "w"), indent=1)
     print(json.dumps({k: v["derived"] for k, v in sq.items()}, indent=1))

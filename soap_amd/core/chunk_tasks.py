@@ -293,12 +293,15 @@ def run_chunk_task(engine, snapshot: SnapshotCells, halo_prop_list: List, cellgr
     return rs
 
 
-def split_halos(halos: Dict[str, np.ndarray], boxsize: float, nr_chunks: int, separate_chunks=None):
+def split_halos(halos: Dict[str, np.ndarray], boxsize: float, nr_chunks: int, separate_chunks=None, weights=None):
     """Halo tables of the chunks: Peano-Hilbert decomposition (domain_decomposition.py), then every chunk's
-    halos in decreasing order of bound-particle count (chunk_tasks.py:118-120)."""
-    from .domain_decomposition import peano_decomposition
+    halos in decreasing order of bound-particle count (chunk_tasks.py:118-120).  `weights`: equal total weight per chunk
+    instead of the reference's equal halo count (`domain_decomposition.halo_work_weights`; "work" uses it)."""
+    from .domain_decomposition import halo_work_weights, peano_decomposition
 
-    ordered, chunk_size = peano_decomposition(boxsize, halos, nr_chunks, separate_chunks)
+    if isinstance(weights, str) and weights == "work":
+        weights = halo_work_weights(halos)
+    ordered, chunk_size = peano_decomposition(boxsize, halos, nr_chunks, separate_chunks, weights=weights)
     out = []
     first = 0
     for size in chunk_size:

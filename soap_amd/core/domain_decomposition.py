@@ -102,7 +102,7 @@ def peano_hilbert_keys(ix, iy, iz, bits: int) -> np.ndarray:
 
 def peano_decomposition(boxsize: float, halo: Dict[str, np.ndarray], nr_chunks: int,
                         separate_chunks: Optional[Sequence[Dict]] = None,
-                        bits_per_dimension: int = 10) -> Tuple[Dict[str, np.ndarray], np.ndarray]:  # fmt: skip
+                        bits_per_dimension: int = 10, weights=None) -> Tuple[Dict[str, np.ndarray], np.ndarray]:  # fmt: skip
     """
     Order the halo table along the Peano-Hilbert curve and cut it into chunks of (almost) equal
     halo count (domain_decomposition.py:64-142).  `halo` is a dict of NumPy arrays with at least
@@ -110,9 +110,17 @@ def peano_decomposition(boxsize: float, halo: Dict[str, np.ndarray], nr_chunks: 
     `separate_chunks`: list of {"n_bound_threshold": int, "n_halo_per_chunk": int} sorted by
     decreasing threshold (parameter_file.py `separate_chunks`); halos above the smallest threshold
     leave the curve and are appended in chunks of their own, most bound particles first.
+    `weights` (one positive number per halo, e.g. `halo_work_weights`): cut the curve into chunks of (almost) equal
+    TOTAL WEIGHT instead of equal halo count -- an option of this engine for one-rank-per-GPU runs, where a chunk is a
+    rank's whole job and nothing is handed out dynamically; the default (None) is the reference's equal-count cut
+    (domain_decomposition.py:135-140).
     Returns (halo table in chunk order, chunk_size array).
     """
     halo = {k: np.asarray(v) for k, v in halo.items()}
+    if weights is not None:
+        halo = dict(halo, _weight=np.asarray(weights, dtype=np.float64))
+        if halo["_weight"].shape[0] != halo["cofp"].shape[0] or np.any(halo["_weight"] <= 0.0):
+            raise ValueError("weights: one positive number per halo")
     total_nr_halos = halo["cofp"].shape[0]
     large = None
     if separate_chunks:
@@ -146,9 +154,28 @@ def peano_decomposition(boxsize: float, halo: Dict[str, np.ndarray], nr_chunks: 
             i_halo += c
         halo = {k: np.concatenate([halo[k], large[k]], axis=0) for k in halo}
     chunk_size = np.zeros(nr_chunks + len(large_halo_chunk_size), dtype=np.int64)
-    if nr_chunks:
+    if nr_chunks and weights is not None:
+        # boundaries where the cumulative weight along the curve passes k / nr_chunks of the total; every chunk keeps a halo
+        cw = np.cumsum(halo["_weight"][:total_nr_small_halos])
+        cuts = np.searchsorted(cw, cw[-1] * np.arange(1, nr_chunks) / nr_chunks, side="left") + 1
+        for k in range(nr_chunks - 1):   # strictly increasing, and room for one halo in every later chunk
+            lo = 1 if k == 0 else cuts[k - 1] + 1
+            cuts[k] = min(max(cuts[k], lo), total_nr_small_halos - (nr_chunks - 1 - k))
+        chunk_size[:nr_chunks] = np.diff(np.concatenate([[0], cuts, [total_nr_small_halos]]))
+    elif nr_chunks:
         chunk_size[:nr_chunks] = total_nr_small_halos // nr_chunks
         chunk_size[: total_nr_small_halos % nr_chunks] += 1
     chunk_size[nr_chunks:] = large_halo_chunk_size
-    assert np.sum(chunk_size) == total_nr_halos
+    assert np.sum(chunk_size) == total_nr_halos and (total_nr_small_halos == 0 or np.all(chunk_size[:nr_chunks] > 0))
+    halo.pop("_weight", None)
     return halo, chunk_size
+
+
+def halo_work_weights(halo: Dict[str, np.ndarray], per_halo: float = 64.0) -> np.ndarray:
+    """
+    A work estimate per halo for the weighted cut, from catalogue columns alone: the engine's time per halo is close to
+    linear in the particles of its search sphere with a fixed part per halo (on C3 the small-halo
+    class and the thread-group classes both come out at ~0.3 ns per bound particle on one MI355X), so
+    w = nr_bound_part + per_halo.
+    """
+    return np.asarray(halo["nr_bound_part"], dtype=np.float64) + float(per_halo)

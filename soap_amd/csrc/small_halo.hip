@@ -1076,7 +1076,7 @@ __device__ __forceinline__ void small_flow_one(const CAS RunParams &P, GAS doubl
 
 // ======================= the kernel =======================================================================================
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWPE, 8)))
-k_small(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo) {
+SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo) {   // k_small128d / k_small512d: the variants show under their own names in a kernel trace
     const CAS RunParams &P = *(const CAS RunParams *)Pp;
     const int ncalc = P.ncalc;
     const long long ncols = P.ncols;
@@ -1497,5 +1497,5 @@ k_small(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo)
 }  // namespace
 
 extern "C" void SOAP_CAT4(soap_launch_small_, SNS, SVAR, )(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo) {
-    hipLaunchKernelGGL(k_small, dim3(groups), dim3(64), 0, stream, params, queue, todo, n_todo);
+    hipLaunchKernelGGL(SOAP_CAT4(k_small, SNS, SVAR, ), dim3(groups), dim3(64), 0, stream, params, queue, todo, n_todo);
 }

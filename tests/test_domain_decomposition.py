@@ -145,3 +145,39 @@ def test_snapshot_cells_rejects_unsorted_particles_and_sorts_on_request():
     got = snap.read_masked_cells(mask)[1]
     want = np.all(np.floor(pos / 2.5).astype(int) == [1, 2, 3], axis=1)
     assert sorted(got["Masses"]) == sorted(np.arange(500.0)[want])
+
+
+def test_weighted_cut_balances_total_weight_and_keeps_the_curve_order():
+    """`weights`: same Peano-Hilbert order, boundaries at equal cumulative weight; without weights the reference's equal-count cut"""
+    from soap_amd.core.domain_decomposition import halo_work_weights
+
+    rng = np.random.default_rng(8)
+    n, L, nc = 5000, 80.0, 8
+    halos = {"cofp": rng.uniform(0, L, (n, 3)), "index": np.arange(n, dtype=np.int64),
+             "nr_bound_part": np.maximum(20, (20.0 * rng.pareto(0.9, n)).astype(np.int64))}  # fmt: skip
+    w = halo_work_weights(halos)
+    assert np.array_equal(w, halos["nr_bound_part"] + 64.0)
+    plain, size0 = peano_decomposition(L, halos, nc)
+    weighted, size1 = peano_decomposition(L, halos, nc, weights=w)
+    assert "_weight" not in weighted and np.array_equal(plain["index"], weighted["index"])   # same order along the curve
+    assert size0.max() - size0.min() <= 1 and size1.sum() == n and np.all(size1 > 0)
+    wo = halo_work_weights(weighted)
+    share = lambda size: np.array([wo[a:b].sum() for a, b in zip(np.cumsum(size) - size, np.cumsum(size))])   # noqa: E731
+    s0, s1 = share(size0), share(size1)
+    # no chunk is heavier than the ideal share plus one halo
+    assert s1.max() <= wo.sum() / nc + wo.max() + 1e-9
+    assert s1.max() < s0.max()
+    # split_halos hands the chunks out, heaviest halo first inside each
+    parts = chunk_tasks.split_halos(halos, L, nc, weights="work")
+    assert [len(p["index"]) for p in parts] == list(size1)
+    assert all(np.all(np.diff(p["nr_bound_part"]) <= 0) for p in parts)
+    # degenerate cases: one giant weight, more chunks than halos
+    w2 = np.ones(n)
+    w2[n // 2] = 1e9
+    _, size2 = peano_decomposition(L, halos, nc, weights=w2)
+    assert size2.sum() == n and np.all(size2 > 0)
+    few = {k: v[:3] for k, v in halos.items()}
+    _, size3 = peano_decomposition(L, few, nc, weights=np.ones(3))
+    assert list(size3) == [1, 1, 1]
+    with pytest.raises(ValueError):
+        peano_decomposition(L, halos, nc, weights=np.zeros(n))
