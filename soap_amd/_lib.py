@@ -105,12 +105,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SOAP_ENGINE_LIB", LIB_PATH)   # (another build of the same sources, e.g. scripts/build_variant.sh)
+    if not os.path.exists(path):
         raise EngineLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (there is no CPU fallback)"
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype

@@ -59,17 +59,21 @@ def mask_cells(cell_size, dimension, centre, radius, done) -> np.ndarray:
     pos_max = c + r[:, None] + 0.5 * cell_size[None, :]
     imin = np.floor(pos_min / cell_size[None, :]).astype(np.int64)
     imax = np.floor(pos_max / cell_size[None, :]).astype(np.int64)
-    cover = []
-    for d in range(3):
-        dim = dimension[d]
-        # a range that is at least one period long covers every cell of the dimension
-        span = np.minimum(imax[:, d] - imin[:, d] + 1, dim)
-        k = np.arange(dim)[None, :]
-        cover.append(((k - imin[:, d, None]) % dim) < span[:, None])   # [halo, dim]
-    # mask[i, j, k] = any_h cover0[h, i] & cover1[h, j] & cover2[h, k]
-    xy = (cover[0][:, :, None] & cover[1][:, None, :]).reshape(c.shape[0], -1).astype(np.float32)
-    hit = xy.T @ cover[2].astype(np.float32)
-    return (hit > 0).reshape(dimension)
+    # coverage count of the boxes by a 3-D difference array on the doubled grid (a box starts inside the first period and is at
+    # most one period long), folded back onto the periodic grid: O(halos + cells) instead of a [halo, cell] table
+    dims = np.array(dimension, dtype=np.int64)
+    span = np.minimum(imax - imin + 1, dims[None, :])
+    lo = imin % dims[None, :]
+    hi = lo + span
+    diff = np.zeros(tuple(2 * dims + 1), dtype=np.int32)
+    for sx, x in ((1, lo[:, 0]), (-1, hi[:, 0])):
+        for sy, y in ((1, lo[:, 1]), (-1, hi[:, 1])):
+            for sz, z in ((1, lo[:, 2]), (-1, hi[:, 2])):
+                np.add.at(diff, (x, y, z), sx * sy * sz)
+    cnt = diff.cumsum(0).cumsum(1).cumsum(2)[:-1, :-1, :-1]
+    d0, d1, d2 = dimension
+    folded = cnt.reshape(2, d0, 2, d1, 2, d2).sum(axis=(0, 2, 4))
+    return folded > 0
 
 
 def resident_radius(mask: np.ndarray, cell_size, centre, read_radius, factor: float = 1.5, steps: int = 8) -> np.ndarray:
@@ -87,9 +91,11 @@ def resident_radius(mask: np.ndarray, cell_size, centre, read_radius, factor: fl
     dim = np.array(mask.shape)
     cs = np.broadcast_to(np.asarray(cell_size, dtype=np.float64), (3,))
     # number of cells NOT flagged in any box of the 3x tiled grid, from a summed-volume table
-    miss = np.tile(~mask, (3, 3, 3)).astype(np.int64)
-    sv = np.zeros(tuple(3 * dim + 1), dtype=np.int64)
-    sv[1:, 1:, 1:] = miss.cumsum(0).cumsum(1).cumsum(2)
+    miss = np.tile(~mask, (3, 3, 3)).astype(np.int32)   # (27 x ncell < 2^31)
+    sv = np.zeros(tuple(3 * dim + 1), dtype=np.int32)
+    np.cumsum(miss, axis=0, out=miss)
+    np.cumsum(miss, axis=1, out=miss)
+    np.cumsum(miss, axis=2, out=sv[1:, 1:, 1:])
 
     def missing(lo, hi):   # inclusive index boxes in the tiled grid
         x0, y0, z0 = lo[:, 0], lo[:, 1], lo[:, 2]

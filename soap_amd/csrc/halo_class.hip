@@ -22,11 +22,17 @@
 #define GWG 256
 #if GMODE == 3
 #define GCH 2048           // the tile-parallel build sorts bucket groups of at most this many entries: less LDS, more groups per CU
+#elif defined(G256_CH)
+#define GCH G256_CH        // (experiments: scripts/build_variant.sh)
 #else
 #define GCH 4096
 #endif
 #define SORT_NBMAX 256
+#ifdef G256_LB
+#define GLB G256_LB
+#else
 #define GLB 2
+#endif
 #define SCAN_E 4
 #define GATTR __launch_bounds__(GRP, GLB)
 #define GSYNC() __syncthreads()
