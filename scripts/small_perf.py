@@ -12,10 +12,14 @@ sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda
 cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
 hn = {k: v.cpu().numpy() for k, v in halos.items()}
 H = len(hn["index"])
+SMALL_ENV = os.environ.get("SOAP_ENGINE_SMALL")
 configs = os.environ.get("CONFIGS", "only3,only0,only1,only2,all,nosmall").split(",")
 for cfg in configs:
-    for k in ("SOAP_ENGINE_ONLY_CLASS", "SOAP_ENGINE_SMALL"):
-        os.environ.pop(k, None)
+    os.environ.pop("SOAP_ENGINE_ONLY_CLASS", None)
+    if SMALL_ENV is None:
+        os.environ.pop("SOAP_ENGINE_SMALL", None)
+    else:
+        os.environ["SOAP_ENGINE_SMALL"] = SMALL_ENV   # (the caller's choice, except in the "nosmall" configuration)
     if cfg.startswith("only"):
         os.environ["SOAP_ENGINE_ONLY_CLASS"] = cfg[4:]
     if cfg == "nosmall":

@@ -358,6 +358,8 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s);
 // the small-halo class (small_halo.hip): one wavefront per halo, slab in LDS; variants by slab entries and chunk content
 void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+void soap_launch_small_128i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+void soap_launch_small_512i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
@@ -1282,10 +1284,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     std::vector<int> todo_small[2];
     const long long small_ns[2] = {128, 512};
     {
-        bool small_ok = !want_inertia && !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
+        bool small_ok = !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
                         P.profile != 1 && h->cfg.slab_capacity <= 0;
-        for (int c = 0; c < n_calcs; c++)
+        int n_tensor_calcs = 0;   // (the inertia pass of the small-halo kernels holds the states of up to 16 calculations in its 64 lanes)
+        for (int c = 0; c < n_calcs; c++) {
             if (calcs[c].kind == SOAP_CALC_PROJECTED || (calcs[c].flags & SOAP_CALC_FLAG_ROTATION)) small_ok = false;
+            if ((calcs[c].flags & SOAP_CALC_FLAG_INERTIA) && calcs[c].kind <= SOAP_CALC_SO_MULTIPLE) n_tensor_calcs++;
+        }
+        if (n_tensor_calcs > 16) small_ok = false;
+        if (want_inertia && getenv("SOAP_ENGINE_SMALL_INERTIA") && atoi(getenv("SOAP_ENGINE_SMALL_INERTIA")) == 0) small_ok = false;
         // SOAP_ENGINE_SMALL: 0 off; 4 (default) EVERY halo of the wavefront class goes through the small-halo kernels -- the
         // 128-entry one where the bound-particle count says so, the 512-entry one otherwise -- and what does not fit is handed on
         // (C3: 17.5 ms of halo kernels against 20.3 with the larger halos on the wavefront class from the start: its 2048
@@ -1384,6 +1391,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         return 0;
     };
     int groups_small[2] = {256 * 11, 256 * 8};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight)
+    if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) groups_small[0] = groups_small[1] = atoi(e); }
     { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
     auto launch_small = [&](int v, std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
@@ -1402,7 +1410,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipEventRecord(C.start, cs));
         C.nh += nt;
         const int ng = (int)std::min<long long>(groups_small[v], nt);
-        if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        if (want_inertia) {   // the variants with the inertia tensor pass (more LDS per wave: fewer waves per CU)
+            if (v == 0) soap_launch_small_128i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+            else soap_launch_small_512i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         else soap_launch_small_512d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));

@@ -54,8 +54,13 @@
 
 #define SOAP_CAT4_(a, b, c, d) a##b##c##d
 #define SOAP_CAT4(a, b, c, d) SOAP_CAT4_(a, b, c, d)
+#ifndef SINERTIA
+#define SINERTIA 0             // 1: the inertia tensor pass compiled in (its LDS and registers stay out of the variant every other run uses)
+#endif
 #if SHYDRO
 #define SVAR h
+#elif SINERTIA
+#define SVAR i
 #else
 #define SVAR d
 #endif
@@ -76,6 +81,9 @@ struct SmallWave {
     // stage B
     double prefc[SPREFB][SMOM];   // prefix moments of up to SPREFB calculations
     int bnd[MAXCALC];             // prefix lengths of a family's calculations in ascending order
+#if SINERTIA
+    double it_par[64][12];        // inertia tensors: eigenvectors (9) and reciprocal semi-axes (3) of the 64 states, read by every lane in the sweeps
+#endif
     // per-halo context, named as in halo_kernel.inc (the shared includes read them through g_S)
     double c[3], L, shift[3];
     double nu_density, a, mpc, mpc20, G_eff;
@@ -1074,6 +1082,218 @@ __device__ __forceinline__ void small_flow_one(const CAS RunParams &P, GAS doubl
     }
 }
 
+#if SINERTIA
+// ======================= inertia tensors (property_calculation/inertia_tensors.py:19-132) ================================
+// As inertia_pass of halo_kernel.inc, for a slab that lives in LDS: a STATE is (calculation, iterative /
+// fixed sphere, plain / reduced) -- dark-matter-only chunks, so the only component is "all particles" and the dark matter
+// tensors are copies -- and state (group g, row r) belongs to lane 16 r + g.  The four states of a group (two calculations x
+// plain / reduced, all iterative or all fixed) sweep the particles together, lanes = particles; wave_sum4 leaves the total of
+// the r-th argument in row r, i.e. exactly in the state's own lane: no hand-over.  Shapes, convergence tests and the 3x3
+// eigenproblems of all 64 states run side by side, one per lane.  Up to 16 calculations with tensors (engine.hip checks).
+
+// eigenvalues (ascending) and eigenvectors of a symmetric 3x3 matrix, cyclic Jacobi rotations as eigh3 of halo_kernel.inc
+// (same operations in the same order), without indexed arrays: every lane solves its own matrix.  V[3 j + k] = component j of
+// eigenvector k.
+SOAP_DEV void small_eigh3(const double t6[6], double ev[3], double V[9]) {
+    double a00 = t6[0], a11 = t6[1], a22 = t6[2], a01 = t6[3], a02 = t6[4], a12 = t6[5];
+    double v00 = 1.0, v01 = 0.0, v02 = 0.0, v10 = 0.0, v11 = 1.0, v12 = 0.0, v20 = 0.0, v21 = 0.0, v22 = 1.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 16; sweep++) {
+        const double off = (a01 * a01 + a02 * a02) + a12 * a12;
+        const double dia = (a00 * a00 + a11 * a11) + a22 * a22;
+        const bool go = off > 1e-60 * dia;
+        if (!__ballot(go)) break;
+#define JACOBI_ROT(app, aqq, apq, arp, arq, v0p, v0q, v1p, v1q, v2p, v2q)                      \
+        if (go && apq != 0.0) {                                                              \
+            const double theta = (aqq - app) / (2.0 * apq);                                  \
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+            const double cc = 1.0 / sqrt(tt * tt + 1.0), ss = tt * cc;                       \
+            app -= tt * apq; aqq += tt * apq; apq = 0.0;                                     \
+            const double rp = arp, rq = arq;                                                 \
+            arp = cc * rp - ss * rq; arq = ss * rp + cc * rq;                                \
+            double vp, vq;                                                                   \
+            vp = v0p; vq = v0q; v0p = cc * vp - ss * vq; v0q = ss * vp + cc * vq;            \
+            vp = v1p; vq = v1q; v1p = cc * vp - ss * vq; v1q = ss * vp + cc * vq;            \
+            vp = v2p; vq = v2q; v2p = cc * vp - ss * vq; v2q = ss * vp + cc * vq;            \
+        }
+        JACOBI_ROT(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21)
+        JACOBI_ROT(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22)
+        JACOBI_ROT(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22)
+#undef JACOBI_ROT
+    }
+    // ascending eigenvalues, columns follow: the three compare-and-swap steps of eigh3's index sort
+#define EIG_SWAP(ea, eb, xa, xb, ya, yb, za, zb)                                                          \
+    if (ea > eb) { double t_; t_ = ea; ea = eb; eb = t_; t_ = xa; xa = xb; xb = t_; t_ = ya; ya = yb; yb = t_; t_ = za; za = zb; zb = t_; }
+    EIG_SWAP(a00, a11, v00, v01, v10, v11, v20, v21)
+    EIG_SWAP(a11, a22, v01, v02, v11, v12, v21, v22)
+    EIG_SWAP(a00, a11, v00, v01, v10, v11, v20, v21)
+#undef EIG_SWAP
+    ev[0] = a00; ev[1] = a11; ev[2] = a22;
+    V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v10; V[4] = v11; V[5] = v12; V[6] = v20; V[7] = v21; V[8] = v22;
+}
+
+__device__ __attribute__((noinline)) void small_inertia(GAS double *row, int kind, int flags, int coloff, int cstate, int cn, int cev, double cR,
+                                                        int ncalc, double nbound_total) {
+    const bool isin = LANE < ncalc && (flags & SOAP_CALC_FLAG_INERTIA) && cstate == 1 && (kind == SOAP_CALC_SUBHALO || (kind >= 0 && kind <= SOAP_CALC_SO_MULTIPLE));
+    const unsigned long long imask = __ballot(isin);
+    const int nic = __popcll(imask);
+    if (nic == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the half-mass radii and masses of the rows were written by other lanes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- this lane's state
+    const int g = LANE & 15, r4 = LANE >> 4;
+    const int mode = g >> 3;                       // 0: iterative (groups 0..7), 1: fixed sphere (groups 8..15)
+    const int o = 2 * (g & 7) + (r4 >> 1);         // ordinal of the calculation among those with tensors
+    const bool reduced = r4 & 1;
+    const bool mine = o < nic;
+    int c = 0;
+    {
+        unsigned long long mm = imask;
+        for (int k = 0; k < 16; k++) if (k < o) mm &= mm - 1;
+        if (mine && mm) c = __ffsll((long long)mm) - 1;
+    }
+    const int c_kind = __shfl(kind, c, 64), c_n = __shfl(cn, c, 64), c_ev = __shfl(cev, c, 64), c_col = __shfl(coloff, c, 64);
+    const double c_R = __shfl(cR, c, 64);
+    const bool bound_only = c_kind == SOAP_CALC_SUBHALO;
+    int n_lim = 0, out = 0;
+    double R = 1.0, nall = 0.0;
+    bool has = false;
+    if (mine) {
+        const GAS double *crow = row + c_col;
+        if (bound_only) {
+            // bound particles, spheres of 10 half-mass radii, no search radius (subhalo_properties.py:1075-1125, :1206-1256)
+            n_lim = c_n; R = 10 * crow[SH_HMR_tot]; has = crow[SH_Mtot] != 0.0; nall = nbound_total;
+            out = c_col + SH_inertia + mode * 12 + (reduced ? 6 : 0);
+        } else {
+            // members and surrounding particles for the iterative tensors, members for the fixed sphere (SO_properties.py:620-672, :798-857)
+            n_lim = mode == 0 ? c_ev : c_n; R = c_R; has = crow[SOC_Mdm] != 0.0; nall = (double)n_lim;
+            out = c_col + SOC_inertia + mode * 12 + (reduced ? 6 : 0);
+        }
+    }
+    const int max_iter = mode == 0 ? 20 : 1;
+    const int sflags = (bound_only ? 1 : 0) | (reduced ? 2 : 0);
+    double ev0 = 1.0, ev1 = 1.0, ev2 = 1.0, q = 1000.0;
+    double T[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool active = mine && has, valid = true;
+    {
+        double *S = g_W.it_par[LANE];
+        for (int k = 0; k < 9; k++) S[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        S[9] = S[10] = S[11] = 0.0;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < 20; iter++) {
+        // shape of this iteration's ellipsoid, convergence test (:82-96)
+        double rlim = 0.0;
+        if (active && iter >= max_iter) active = false;
+        if (active) {
+            const double old_q = q;
+            q = sqrt(ev1 / ev2);
+            const double s = sqrt(ev0 / ev2);
+            const double p = sqrt(ev0 / ev1);
+            if (fabs((old_q - q) / q) < 0.0001) active = false;
+            else {
+                // reciprocals of the semi-axes R cbrt(s p), R cbrt(q / p), R / cbrt(q s)  (:99-101)
+                const double ax0 = 1.0 / (R * (1.0 * cbrt(s * p)));
+                const double ax1 = 1.0 / (R * (1.0 * cbrt(q / p)));
+                const double ax2 = 1.0 / (R * (1.0 / cbrt(q * s)));
+                double *S = g_W.it_par[LANE];
+                S[9] = ax0; S[10] = ax1; S[11] = ax2;
+                rlim = 1.0001 / fmin(fmin(ax0, ax1), ax2);   // nothing beyond the longest semi-axis is inside (the slab is sorted by radius)
+            }
+        }
+        WSYNC();
+        const unsigned long long amask = __ballot(active);
+        if (!amask) break;
+        double s_n = 0.0, s_w = 0.0, s_xx = 0.0, s_yy = 0.0, s_zz = 0.0, s_xy = 0.0, s_xz = 0.0, s_yz = 0.0;
+        unsigned gmask = (unsigned)((amask | (amask >> 16) | (amask >> 32) | (amask >> 48)) & 0xffffull);
+#pragma unroll 1
+        while (gmask) {
+            const int gg = __ffs((int)gmask) - 1;
+            gmask &= gmask - 1;
+            bool act[4];
+            int nl[4], sf[4];
+            int nmax = 0;
+            double rmax = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int L = 16 * rr + gg;
+                act[rr] = (amask >> L) & 1ull;
+                nl[rr] = rl(n_lim, L); sf[rr] = rl(sflags, L);
+                const double rl_ = rl64(rlim, L);
+                if (act[rr]) { nmax = max(nmax, nl[rr]); rmax = fmax(rmax, rl_); }
+            }
+            const int ncut = min(nmax, count_r_le(nmax, rmax));
+            double acc[4][8];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[rr][k] = 0.0;
+#pragma unroll 1
+            for (int e = 0; e < SE; e++) {
+                if (64 * e >= ncut) break;
+                const int i = 64 * e + LANE;
+                const bool ok = i < ncut;
+                const int ii = ok ? i : 0;
+                const int fl = g_W.flags[ii];
+                const double x = CX(dx)[ii], y = CX(dy)[ii], z = CX(dz)[ii], w = CX(m)[ii];
+                const double rr_ = g_W.r[ii];
+                const double norm = rr_ * rr_;              // np.linalg.norm(x, axis=1) ** 2  (:63)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    if (!act[rr]) continue;                  // (uniform)
+                    const double *S = g_W.it_par[16 * rr + gg];
+                    const double p0 = ((x * S[0] + y * S[3]) + z * S[6]) * S[9];
+                    const double p1 = ((x * S[1] + y * S[4]) + z * S[7]) * S[10];
+                    const double p2 = ((x * S[2] + y * S[5]) + z * S[8]) * S[11];
+                    const double re = sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+                    const bool in = ok && i < nl[rr] && !((sf[rr] & 1) && !(fl & FL_BOUND)) && !((sf[rr] & 2) && norm <= 1e-8) && re <= 1.0;   // np.isclose(norm, 0)  (:64)
+                    const double ww = in ? ((sf[rr] & 2) ? w / norm : w) : 0.0;
+                    acc[rr][0] += in ? 1.0 : 0.0; acc[rr][1] += in ? w : 0.0;
+                    acc[rr][2] += ww * x * x; acc[rr][3] += ww * y * y; acc[rr][4] += ww * z * z;
+                    acc[rr][5] += ww * x * y; acc[rr][6] += ww * x * z; acc[rr][7] += ww * y * z;
+                }
+            }
+            // totals: row r of each packed register holds the sum of state (gg, r), i.e. its own lane's
+            const double t0 = wave_sum4(acc[0][0], acc[1][0], acc[2][0], acc[3][0]), t1 = wave_sum4(acc[0][1], acc[1][1], acc[2][1], acc[3][1]);
+            const double t2 = wave_sum4(acc[0][2], acc[1][2], acc[2][2], acc[3][2]), t3 = wave_sum4(acc[0][3], acc[1][3], acc[2][3], acc[3][3]);
+            const double t4 = wave_sum4(acc[0][4], acc[1][4], acc[2][4], acc[3][4]), t5 = wave_sum4(acc[0][5], acc[1][5], acc[2][5], acc[3][5]);
+            const double t6 = wave_sum4(acc[0][6], acc[1][6], acc[2][6], acc[3][6]), t7 = wave_sum4(acc[0][7], acc[1][7], acc[2][7], acc[3][7]);
+            if (g == gg) { s_n = t0; s_w = t1; s_xx = t2; s_yy = t3; s_zz = t4; s_xy = t5; s_xz = t6; s_yz = t7; }
+        }
+        bool fresh = false;
+        if (active) {
+            // fewer than 20 particles in all, or inside the initial sphere: no tensor (:57-58, :106-107)
+            if (iter == 0 && (nall < 20.0 || s_n < 20.0)) { valid = false; active = false; }
+            else if (!(s_w != 0.0)) { for (int k = 0; k < 6; k++) T[k] = 0.0; active = false; }
+            else {
+                T[0] = s_xx / s_w; T[1] = s_yy / s_w; T[2] = s_zz / s_w; T[3] = s_xy / s_w; T[4] = s_xz / s_w; T[5] = s_yz / s_w;
+                fresh = true;
+            }
+        }
+        {
+            // (the eigenproblems of all lanes together: lanes without a fresh tensor carry theirs along and keep their state)
+            double ev[3], Vn[9];
+            small_eigh3(T, ev, Vn);
+            if (fresh) {
+                double *S = g_W.it_par[LANE];
+                for (int k = 0; k < 9; k++) S[k] = Vn[k];
+                ev0 = fabs(ev[0]); ev1 = fabs(ev[1]); ev2 = fabs(ev[2]);
+                if (q == 0.0) { for (int k = 0; k < 6; k++) T[k] = 0.0; active = false; }   // :127-129
+            }
+        }
+        WSYNC();
+    }
+    // columns: mode * 12 + reduced * 6; the dark matter tensors of a dark-matter-only chunk are the total ones
+    if (mine) {
+        for (int k = 0; k < 6; k++) {
+            const double val = (valid && has) ? T[k] : 0.0;
+            row[out + k] = val;
+            if (has) row[out + 24 + k] = val;
+        }
+    }
+}
+#endif   // SINERTIA
+
 // ======================= the kernel =======================================================================================
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWPE, 8)))
 SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo) {   // k_small128d / k_small512d: the variants show under their own names in a kernel trace
@@ -1345,6 +1565,11 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                             res = so_eval_lane(cdf, Rcur, n, nskip, rp, -1, &creq, &st, &nin, &Rv, &Mv);
 #endif
                         }
+#if SINERTIA
+                        // iterative inertia tensors: "if np.max(R) > search_radius: raise" (inertia_tensors.py:110-111) is reached when the
+                        // sphere holds at least 20 particles, all of which then lie inside R
+                        if (pending && res == RES_OK && st == 1 && (cdf.flags & SOAP_CALC_FLAG_INERTIA) && cdf.kind != SOAP_CALC_SUBHALO && Rv > Rcur && n >= 20) res = RES_TOO_SMALL;
+#endif
                         const unsigned long long failm = __ballot(pending && res != RES_OK);
                         const int f = failm ? __ffsll((long long)failm) - 1 : 64;
                         const bool commit = pending && c < f;
@@ -1449,6 +1674,10 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                 }
 #endif
             }
+#if SINERTIA
+            __builtin_amdgcn_sched_barrier(0);
+            small_inertia(row, cd.kind, cd.flags, coloff, cs.state, cs.n, cs.ev, cs.R, ncalc, nbound_total);
+#endif
             // exclusive spheres that repeat the next-smaller one (aperture_properties.py:4117-4123): copies of its columns
             {
                 unsigned long long cp = __ballot(LANE < ncalc && cs.state == 3);

@@ -944,7 +944,8 @@ class _InertiaOff:
         return {n: (False if "InertiaTensor" in n else "basic") for n in names}
 
 
-def test_inertia_tensors(built_library, monkeypatch):
+@pytest.mark.parametrize("small", ["0", "4"], ids=["thread-group-classes", "small-halo-class"])
+def test_inertia_tensors(built_library, monkeypatch, small):
     """Total / dark matter inertia tensors of the bound subhalo and of SOs (inertia_tensors.py:19-132):
     iterative ellipsoids that reach into the particles surrounding the SO, fixed-sphere versions, reduced
     versions; fewer than 20 particles give zeros.  Switched off in the parameter file, their 96 columns per
@@ -956,7 +957,9 @@ def test_inertia_tensors(built_library, monkeypatch):
                "5xR_200_crit": {"value": 200.0, "type": "crit", "radius_multiple": 5.0}}  # fmt: skip
     props = chp.build_halo_prop_list(sc, cf, so_vars, {})
     assert all(p.calc_desc(props, i).flags & layout.CALC_FLAG_INERTIA for i, p in enumerate(props))
+    monkeypatch.setenv("SOAP_ENGINE_SMALL", small)   # "4": the halos of the wavefront class go through the small-halo kernels' own tensor pass
     engine, ha, results, out = _run_engine(sc, data_np, halos_np, props)
+    assert (engine.kernel_ms("n_small") > 0) == (small == "4")
     ref, stats, ha_ref = helpers.run_oracle(sc, data_np, halos_np, cf, so_vars, {})
     assert np.array_equal(ha["done"], ha_ref["done"])
     done_rows = np.flatnonzero(ha["done"] == 1)

@@ -149,3 +149,31 @@ def test_small_class_so_membership_is_exact(built_library, monkeypatch):
             if key == "Ndm":
                 assert np.array_equal(helpers.engine_value(res[j], group, key), val.raw), (row, okey)
     engine.close()
+
+
+def test_small_class_inertia_tensors_equal_the_general_path(built_library, monkeypatch):
+    """the tensor pass of the small-halo kernels (lanes = tensors for shapes and eigenproblems, lanes = particles for the sweeps)
+    against the thread-group classes: same selections, same iterations -- the tensors agree to rounding -- for the default list
+    (bound subhalo + 9 SOs, 40 tensors per halo) and with halos that are handed on"""
+    sc, data, halos = make_chunk(250000, 300, seed=74, satellite_fraction=0.1)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)))   # default parameters: the tensors are on
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha0, res0, raw0, t0, (n0, _) = _run(engine, props, sc, halos_np, 0, monkeypatch)
+    ha4, res4, raw4, t4, (n4, e4) = _run(engine, props, sc, halos_np, 4, monkeypatch)
+    ha2, res2, raw2, t2, (n2, e2) = _run(engine, props, sc, halos_np, 2, monkeypatch)   # 128-entry slabs for everybody: many are handed on
+    engine.close()
+    assert n0 == 0 and n4 > 0.5 * len(halos_np["index"]) and e2 > 0
+    for ha, raw, t in ((ha4, raw4, t4), (ha2, raw2, t2)):
+        _same_selections(ha, raw, ha0, raw0)
+        scale = np.maximum(np.maximum(np.abs(t), np.abs(t0)).max(axis=0, keepdims=True), 1e-300)
+        assert np.all(np.abs(t - t0) <= 1e-9 * np.abs(t0) + 1e-12 * scale)
+    ntens = 0
+    for r in res4:
+        for grp in ("BoundSubhalo", "SO/200_crit", "SO/2500_crit", "SO/5xR_500_crit"):
+            it = r[f"{grp}/TotalInertiaTensor"][4]
+            ntens += int(np.any(it))
+            assert np.array_equal(r[f"{grp}/DarkMatterInertiaTensor"][4], it)
+    assert ntens > 300
