@@ -1480,9 +1480,39 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
     }
     if (hybrid) for (int k = 1; k < 3; k++) early[k].swap(todo[k]);
+    // behind the small-halo kernels (and behind the wavefront class' own launch: same stream, same slab): the wavefront class once
+    // more, for the rows that were handed on
+    auto launch_cleanup = [&](bool join) -> int32_t {
+        if (P.small_esc == nullptr || (todo_small[0].empty() && todo_small[1].empty())) return 0;
+        soap_engine::Class &C = h->cls[0];
+        hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
+        int rc2 = alloc_slab(C, caps[0], groups[0]);
+        if (rc2) return rc2;
+        for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(cs, h->small[v].done, 0));
+        HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+        const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size()));
+        if (C.nh == 0) HIPCHECK(hipEventRecord(C.start, cs));   // (no launch of the class' own in this run: its clock starts here)
+        if (!want_inertia) soap_launch_halo_64n(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+        else soap_launch_halo_64i(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+        HIPCHECK(hipEventRecord(C.done, cs));
+        if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+        return 0;
+    };
+    int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
+    { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
+    bool small_early = false;
     if (hybrid || giants) {
         int rc = launch_single(early, h->ev_p[0], false);
         if (rc) return rc;
+        // ... and the small-halo kernels with them: launched after the pipeline's iterations (whose host loop waits for every
+        // iteration's verdicts) they and the clean-up launch behind them were a serial tail of ~2.4 ms on an eighth of the C3 box
+        static const bool small_late = getenv("SOAP_ENGINE_SMALL_LATE") && atoi(getenv("SOAP_ENGINE_SMALL_LATE")) != 0;
+        if (!small_late && only_class < 0) {
+            for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev_p[0], false);
+            if (!rc) rc = launch_cleanup(false);
+            if (rc) return rc;
+            small_early = true;
+        }
     }
     if (pipeline) {
         TRACE("pipeline: begin");
@@ -1800,8 +1830,6 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     }
     TRACE("run: single-kernel part");
     h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size());
-    int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
-    { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
     h->n_passes = 0;
@@ -1833,29 +1861,17 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // small-halo class (three per SIMD fill its registers) would never leave one
             static const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
             int rc = 0;
-            if (small_first) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
+            const bool launch_small_now = !(small_early && pass == 0);   // (giants' mode: they started before the pipeline)
+            if (small_first && launch_small_now) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
             if (rc) return rc;
             rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
-            if (!small_first) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
+            if (!small_first && launch_small_now) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
             if (rc) return rc;
+            if (!launch_small_now) for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(st, h->small[v].done, 0));
             for (int v = 0; v < 2; v++) any = any || !todo_small[v].empty();
-            if (P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) {
-                // behind the small-halo kernels (and behind the wavefront class' own launch of this pass: same stream, same
-                // slab): the wavefront class once more, for the rows that were handed on
-                soap_engine::Class &C = h->cls[0];
-                hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
-                int rc2 = alloc_slab(C, caps[0], groups[0]);
-                if (rc2) return rc2;
-                for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(cs, h->small[v].done, 0));
-                HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
-                const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size()));
-                if (todo[0].empty()) HIPCHECK(hipEventRecord(C.start, cs));
-                if (!want_inertia) soap_launch_halo_64n(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
-                else soap_launch_halo_64i(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
-                HIPCHECK(hipEventRecord(C.done, cs));
-                HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
-            }
+            if (launch_small_now) { const int rc3 = launch_cleanup(true); if (rc3) return rc3; }
+            else if (P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) HIPCHECK(hipStreamWaitEvent(st, h->cls[0].done, 0));
         }
         if (pass == 0) {
             // the large halos launched before the pipeline stages: their statuses are checked with this pass
