@@ -568,6 +568,7 @@ struct soap_engine {
     double ms_host_pre = 0, ms_host_setup = 0, ms_host_classify = 0, ms_host_total = 0;   // wall clock inside run()
     unsigned *d_queue = nullptr;
     RunParams *d_params = nullptr;
+    RunParams *d_params_pipe = nullptr;   // the pipeline's own copy: its iterations rewrite hdr / tile tables while class and small-halo kernels of the same run read d_params
     unsigned long long *d_phase = nullptr;
     unsigned long long phase[32] = {};
     // per-class slabs/queues: class 0 = one wavefront per halo, 1 = 256 threads, 2 = 1024 threads
@@ -758,6 +759,7 @@ static int32_t create_resources(soap_engine *h) {
         }
     }
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
+    HIPCHECK(hipMalloc((void **)&h->d_params_pipe, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
     for (int k = 0; k < 6; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
     return 0;
@@ -808,6 +810,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_coloff) (void)hipFree(h->d_coloff);
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_params_pipe) (void)hipFree(h->d_params_pipe);
     if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->d_hdr) (void)hipFree(h->d_hdr);
     if (h->d_gb) (void)hipFree(h->d_gb);
@@ -1533,7 +1536,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         P.rebuild_factor = giants ? 1.6 : 1.25;   // (stage A already extrapolates the enclosed density to the target; giants: every extra iteration is a round of launches for a handful of halos)
         { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) P.rebuild_factor = atof(e); }
         P.g_coarse = getenv("SOAP_ENGINE_G_COARSE") != nullptr && atoi(getenv("SOAP_ENGINE_G_COARSE")) != 0;
-        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
         auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after, bool join, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int alt = -1) -> int32_t {
             const int order[3] = {2, 1, 0};
             for (int oi = 0; oi < 3; oi++) {
@@ -1554,7 +1557,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
                 HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
                 const int nwg = (int)std::min<long long>(groups[k], nt);
-                const RunParams *dp = h->d_params;
+                const RunParams *dp = h->d_params_pipe;
                 if (timed) HIPCHECK(hipEventRecord(C.pstart[mode == 1 ? 0 : 1], cs));
                 if (e0 && k == 2) HIPCHECK(hipEventRecord(e0, cs));
                 if (mode == 1) {
@@ -1604,7 +1607,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (iter > 0) {
                 // new work estimates for the enlarged spheres; the classes follow them
                 HIPCHECK(hipMemcpyAsync(d_rbuild, rbuild.data(), n * 8, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est2, (const double *)d_rbuild);
+                hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params_pipe, d_est2, (const double *)d_rbuild);
                 HIPCHECK(hipMemcpyAsync(est.data(), d_est2, n * 8, hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
                 std::vector<int> again[3];
@@ -1713,10 +1716,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     d += parts[q]->size();
                 }
                 P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6]; P.sel_li = dptr[9]; P.gbins = h->d_gbins;
-                HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
+                HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
                 HIPCHECK(hipStreamWaitEvent(h->cls[0].stream, h->ev_p[1], 0));   // (class 0 reads the same parameter block: upload first)
                 HIPCHECK(hipEventRecord(C.pstart[0], cs));
-                soap_launch_gbuild(cs, h->d_params, h->arena, (long long)L, (long long)tile_li.size(), (long long)gblock_li.size(),
+                soap_launch_gbuild(cs, h->d_params_pipe, h->arena, (long long)L, (long long)tile_li.size(), (long long)gblock_li.size(),
                                    (long long)sel_li.size(), dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8], dptr[10], dptr[11]);
                 HIPCHECK(hipEventRecord(C.pdone[0], cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
@@ -1731,7 +1734,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (rc) return rc;
             HIPCHECK(hipEventRecord(h->ev_p[2], st));
             // stage 2: one lane per halo (records that are not freshly built are skipped)
-            soap_launch_stage_a(st, h->d_params, h->arena, nullptr, (long long)n);
+            // the one-lane-per-halo radius loop knows nothing of neutrinos, property radii or the tensors' search-radius rule: runs
+            // with them never get here (the gate above); should the gate and the kernel ever drift apart, fail instead of computing
+            if (P.has_nu || want_inertia || want_property_radius || P.literal) return fail(-102, "pipeline: stage A cannot serve this run (neutrinos / inertia tensors / property radii / literal mode)");
+            soap_launch_stage_a(st, h->d_params_pipe, h->arena, nullptr, (long long)n);
             // large halos whose loop has finished: moment sums of the whole tiles of their search spheres, by all CUs, so that
             // the one or two groups of the property stage only add them up (reduce_span)
             const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
@@ -1743,9 +1749,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     h->bpart_count[iter] = need + need / 4;
                     HIPCHECK(hipMalloc((void **)&h->d_bpart[iter], h->bpart_count[iter] * sizeof(double)));
                 }
-                soap_launch_bpartials(st, h->d_params, h->arena, iter_tiles, h->d_bpart[iter]);
+                soap_launch_bpartials(st, h->d_params_pipe, h->arena, iter_tiles, h->d_bpart[iter]);
             }
-            hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_hdr, (long long)n, d_state, d_rbuild);
+            hipLaunchKernelGGL(k_collect_state, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const RunParams *)h->d_params_pipe, h->d_hdr, (long long)n, d_state, d_rbuild);
             HIPCHECK(hipEventRecord(h->ev_p[3], st));
             HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(rbuild.data(), d_rbuild, n * 8, hipMemcpyDeviceToHost, st));
