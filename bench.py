@@ -69,6 +69,9 @@ WORKLOADS = {
     "giant": dict(n_part=20_000_000, n_halo=2_000, so="default", apertures=(30.0, 50.0, 100.0), max_halo=1_000_000,
                   name="synthetic DMO 2e7 particles / 2e3 halos with the halo size cap lifted to 1e6 particles, "
                        "C3 calculation list; inertia tensors off"),
+    "c3u": dict(n_part=100_000_000, n_halo=100_000, so="default", apertures=(30.0, 50.0, 100.0), max_halo=1_000_000,
+                name="synthetic DMO 1e8 particles / 1e5 halos, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc; "
+                     "inertia tensors off; halo sizes capped at 1e6 particles (the `uncapped` entry of full_set on its own)"),
     "tiny": dict(n_part=400_000, n_halo=400, so="default", apertures=(30.0, 50.0, 100.0),
                  name="synthetic DMO 4e5 particles / 4e2 halos (plumbing check)"),
 }  # fmt: skip

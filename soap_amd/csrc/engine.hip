@@ -1671,7 +1671,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     static const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
                     const bool giant_sort = e > giant_sort_limit;
                     const int ng = giant_sort ? (int)(e / 1024 + 2) : (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
-                    const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / 256), 64) : 0;
+                    // (bins of ~30 entries on average: a bin may hold up to half a block, and the bins at the core of a concentrated halo --
+                    // or across a massive satellite -- hold tens of times the average once the build radius has been doubled twice; with
+                    // ~120 per bin two halos of the uncapped C3 box fell back to ONE 1024-thread group each, 15 ms at the end of the pass)
+                    static const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
+                    const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / giant_bin), 64) : 0;
                     bin_first.push_back(giant_sort ? (int)nbins_total : -1); nbinv.push_back(nbin);
                     if (giant_sort) nbins_total += 2ll * nbin + 1 + ng + 1;
                     first_tile.push_back((int)tile_li.size()); ntile.push_back(nt);
