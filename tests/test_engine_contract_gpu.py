@@ -244,3 +244,31 @@ def test_device_memory_stays_bounded_over_chunks_of_different_sizes(built_librar
     # after the first few chunks the footprint no longer grows with every new size (it did: one cached generation
     # of ~60-110 B per particle per distinct size)
     assert free[-1] >= free[2] - 64 * 2**20, free
+
+
+def test_runs_the_pipeline_cannot_serve_stay_on_the_single_kernel_path(built_library, monkeypatch):
+    """The one-lane-per-halo radius loop of the pipeline (stage_a.hip) knows nothing of the inertia tensors' search-radius rule
+    nor of property-defined aperture radii: a run that carries them must not enter the pipeline even when it is forced on for
+    every halo (SOAP_ENGINE_PIPELINE=2) -- and still gives the answers of the default configuration."""
+    sc, data, halos = make_chunk(150000, 80, seed=41)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    ap = chp.aperture_variations((50.0,))
+    props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}}, ap)   # default parameters: the tensors are on
+    assert any(p.calc_desc(props, i).flags & layout.CALC_FLAG_INERTIA for i, p in enumerate(props))
+
+    def run():
+        engine = halo_tasks.make_engine(sc, device=0)
+        halo_tasks.stage_chunk(engine, data_np)
+        ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(len(halos_np["index"]), dtype=np.int32))
+        out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
+        table = engine.fetch(table=True)["table"]
+        n_pipe = int(engine.kernel_ms("n_pipeline"))
+        engine.close()
+        return table, out[4]["status"], n_pipe
+
+    t0, s0, n0 = run()
+    monkeypatch.setenv("SOAP_ENGINE_PIPELINE", "2")
+    t2, s2, n2 = run()
+    assert n0 == 0 and n2 == 0
+    assert np.array_equal(s0, s2) and np.array_equal(t0, t2)
