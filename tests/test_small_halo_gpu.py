@@ -177,3 +177,21 @@ def test_small_class_inertia_tensors_equal_the_general_path(built_library, monke
             ntens += int(np.any(it))
             assert np.array_equal(r[f"{grp}/DarkMatterInertiaTensor"][4], it)
     assert ntens > 300
+
+
+def test_small_class_inertia_tensors_with_restarts_inside_the_resident_radius(built_library, monkeypatch):
+    """halos whose read radius grows inside the engine (resident region) start again with every calculation open: the tensor
+    states of the small-halo kernels are rebuilt with them"""
+    sc, data, halos = make_chunk(300000, 300, seed=72, read_radius_factor=1.5, satellite_fraction=0.15)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0,)))   # the default SO list (5 x R_500 reaches far out), tensors on
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha0, _, raw0, t0, (n0, _) = _run(engine, props, sc, halos_np, 0, monkeypatch, resident=np.inf)
+    ha4, _, raw4, t4, (n4, _) = _run(engine, props, sc, halos_np, 4, monkeypatch, resident=np.inf)
+    engine.close()
+    assert n0 == 0 and n4 > 0 and np.all(ha4["done"] == 1) and raw4["stats"][:, 5].max() > 1   # some halos needed more than one attempt
+    _same_selections(ha4, raw4, ha0, raw0)
+    scale = np.maximum(np.maximum(np.abs(t4), np.abs(t0)).max(axis=0, keepdims=True), 1e-300)
+    assert np.all(np.abs(t4 - t0) <= 1e-9 * np.abs(t0) + 1e-12 * scale)
