@@ -59,7 +59,7 @@ def _compare_rows(sc, props, coloff, got, ha, rows, ref, stats_ref, ha_ref, no_i
     return len(done), nchecked
 
 
-def _subcube_parity(workload, min_halos, max_halos=None):
+def _subcube_parity(workload, min_halos, max_halos=None, inertia=False):
     import torch
 
     import bench
@@ -69,7 +69,7 @@ def _subcube_parity(workload, min_halos, max_halos=None):
     wl = bench.WORKLOADS[workload]
     sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0", hydro=wl.get("hydro", False),
                                  max_halo=wl.get("max_halo"), topcells=bench.TOPCELLS)  # fmt: skip
-    cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
+    cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl, inertia=inertia)
     hn, ha, raw, got, coloff, counts = _engine_pass(sc, data, halos, props)
     print(f"[sample {workload}] engine pass over {len(hn['index'])} halos done: {time.time() - t0:.1f} s, paths {counts}", flush=True)
     rows, d_np, h_np, frac = bench.subcube_sample(sc, data, halos)
@@ -81,7 +81,7 @@ def _subcube_parity(workload, min_halos, max_halos=None):
         rows, h_np = rows[keep], {k: v[keep] for k, v in h_np.items()}
     assert len(rows) >= min_halos, (len(rows), min_halos)
     saved = ho.ENABLE_INERTIA
-    ho.ENABLE_INERTIA = False   # the benchmark configurations have the tensors off (bench._NamedPropertySet)
+    ho.ENABLE_INERTIA = inertia   # the benchmark configurations have the tensors off (bench._NamedPropertySet); full_set has them on
     try:
         res = {pt: max(1, int(round(ho.mesh_resolution(int(wl["n_part"])) * frac))) for pt in d_np}
         ref, stats_ref, ha_ref = helpers.run_oracle(sc, d_np, h_np, cf, so_vars, ap_vars, resolution=max(res.values()),
@@ -90,7 +90,7 @@ def _subcube_parity(workload, min_halos, max_halos=None):
         ho.ENABLE_INERTIA = saved
     print(f"[sample {workload}] oracle over {len(rows)} halos of the {frac:.3f} L sub-cube done: {time.time() - t0:.1f} s", flush=True)
     ref_by_pos = [ref[j] for j in np.flatnonzero(ha_ref["done"] == 1)]
-    ndone, nchecked = _compare_rows(sc, props, coloff, got, ha, rows, ref_by_pos, stats_ref, ha_ref, dmo=not wl.get("hydro", False))
+    ndone, nchecked = _compare_rows(sc, props, coloff, got, ha, rows, ref_by_pos, stats_ref, ha_ref, no_inertia=not inertia, dmo=not wl.get("hydro", False))
     print(f"[sample {workload}] {ndone} halos, {nchecked} values compared: {time.time() - t0:.1f} s", flush=True)
     assert ndone >= 0.95 * len(rows)
     return counts
@@ -100,6 +100,14 @@ def test_c3_sample_matches_the_oracle(built_library):
     """C3 at full size (seed 1234, the box of the driver's bench line): >= 2000 halos of the cpu_baseline sub-cube, all 16 calculations"""
     counts = _subcube_parity("c3", min_halos=2000)
     assert counts["n_small"] > 50000   # the sample's small halos went through the small-halo class, as in the bench line
+
+
+def test_c3_sample_with_the_inertia_tensors_matches_the_oracle(built_library):
+    """the `full_set.inertia_on` configuration of the bench line: C3 with the 8 x 6 tensor columns of the bound subhalo and of every
+    SO switched on -- grouped sweeps in the thread-group classes, the lane-per-tensor pass of the small-halo kernels -- against the
+    oracle's iterative tensors on a cut through the sizes of the sub-cube sample"""
+    counts = _subcube_parity("c3", min_halos=600, max_halos=700, inertia=True)
+    assert counts["n_small"] > 50000
 
 
 def test_c5_share_sample_matches_the_oracle(built_library):
