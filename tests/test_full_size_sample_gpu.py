@@ -115,23 +115,25 @@ def test_c5_share_sample_matches_the_oracle(built_library):
     _subcube_parity("c5", min_halos=500, max_halos=1200)
 
 
-def test_giant_workload_largest_halos_match_the_oracle(built_library):
-    """`--workload giant` (halo size cap 1e6 particles): the largest halos -- they go through the multi-workgroup pipeline or the
-    1024-thread class -- each against the oracle run on the particles of its own read sphere"""
+@pytest.mark.parametrize("workload", ["giant", "c3u"])
+def test_giant_workload_largest_halos_match_the_oracle(built_library, workload):
+    """`--workload giant` (2e7 particles) and `c3u` (the C3 box, `full_set.uncapped` of the bench line), halo size cap 1e6 particles:
+    the largest halos -- they go through the multi-workgroup pipeline or the 1024-thread class -- each against the oracle run on the
+    particles of its own read sphere"""
     import torch
 
     import bench
     from oracle import halo_oracle as ho
 
     t0 = time.time()
-    wl = bench.WORKLOADS["giant"]
+    wl = bench.WORKLOADS[workload]
     sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=1234, device="cuda:0", max_halo=wl["max_halo"], topcells=bench.TOPCELLS)
     cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
     hn, ha, raw, got, coloff, counts = _engine_pass(sc, data, halos, props)
-    print(f"[sample giant] engine pass done: {time.time() - t0:.1f} s, paths {counts}", flush=True)
+    print(f"[sample {workload}] engine pass done: {time.time() - t0:.1f} s, paths {counts}", flush=True)
     order = np.argsort(-hn["nr_bound_part"], kind="stable")
     rows = np.sort(order[:10])
-    assert hn["nr_bound_part"][rows].max() >= 500000
+    assert hn["nr_bound_part"][rows].max() >= 400000
     L = sc.boxsize
     saved = ho.ENABLE_INERTIA
     ho.ENABLE_INERTIA = False
@@ -161,7 +163,7 @@ def test_giant_workload_largest_halos_match_the_oracle(built_library):
             s = got["stats"][row]
             assert (s[0], s[1]) == (st["n_loop"], st["n_sel"]), (row, s[:3], st)   # (n_cand counts mesh cells: another mesh here)
             ndone += 1
-            print(f"[sample giant] halo row {row}: {hn['nr_bound_part'][row]} bound, {st['n_sel']} in its sphere: {time.time() - t0:.1f} s", flush=True)
+            print(f"[sample {workload}] halo row {row}: {hn['nr_bound_part'][row]} bound, {st['n_sel']} in its sphere: {time.time() - t0:.1f} s", flush=True)
     finally:
         ho.ENABLE_INERTIA = saved
     assert ndone >= 8 and nchecked > 0
