@@ -965,17 +965,18 @@ __device__ __forceinline__ void small_subhalo_spin(GAS double *row, int n0, doub
         }
     }
     const double p1 = wave_sum4(sm, mx0, mx1, mx2), p2 = wave_sum4(l0, l1, l2, 0.0);
-    double b[NACC];
-    for (int k = 0; k < NACC; k++) b[k] = 0.0;
     const double Mr = rl64(p1, 0);
-    b[A_MX] = rl64(p1, 16); b[A_MX + 1] = rl64(p1, 32); b[A_MX + 2] = rl64(p1, 48);
-    b[A_LA] = rl64(p2, 0); b[A_LA + 1] = rl64(p2, 16); b[A_LA + 2] = rl64(p2, 32);
+    const double bx0 = rl64(p1, 16), bx1 = rl64(p1, 32), bx2 = rl64(p1, 48);
+    const double bl0 = rl64(p2, 0), bl1 = rl64(p2, 16), bl2 = rl64(p2, 32);
     if (LANE == 0 && Mr > 0.0) {
-        double dv[3];
         // row[SH_vcom] - shift, as the general path reads it back
         const double iMt = 1.0 / Mtot;
-        for (int d = 0; d < 3; d++) dv[d] = (mv[d] * iMt + g_S.shift[d]) - g_S.shift[d];
-        row[SH_spin] = norm_L_about(b, dv) / (sqrt(2.0) * Mr * vmax_s * rmax_s);
+        const double dv0 = (mv[0] * iMt + g_S.shift[0]) - g_S.shift[0], dv1 = (mv[1] * iMt + g_S.shift[1]) - g_S.shift[1],
+                     dv2 = (mv[2] * iMt + g_S.shift[2]) - g_S.shift[2];
+        // norm_L_about of halo_finalize.inc on registers (its moment array is read as volatile memory in this file: a local array
+        // would live in scratch)
+        const double lx = bl0 - (bx1 * dv2 - bx2 * dv1), ly = bl1 - (bx2 * dv0 - bx0 * dv2), lz = bl2 - (bx0 * dv1 - bx1 * dv0);
+        row[SH_spin] = sqrt((lx * lx + ly * ly) + lz * lz) / (sqrt(2.0) * Mr * vmax_s * rmax_s);
     }
 }
 
