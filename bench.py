@@ -445,6 +445,7 @@ def main():
             # the small-halo class (one wavefront per halo, slab in LDS): halos that went through its 128- / 512-entry kernels, and
             # how many of them were handed on to the wavefront class (counted there too)
             "halos_small_class": {"slab128": int(engine.kernel_ms("n_small128")), "slab512": int(engine.kernel_ms("n_small512")),
+                                  "slab1024": int(engine.kernel_ms("n_small1024")),
                                   "handed_on": int(engine.kernel_ms("n_small_escalated"))},
         }  # fmt: skip
 
@@ -517,6 +518,7 @@ def main():
             "kernel_ms": {"halo": float(np.mean(ms_halo)), "mesh": float(np.mean(ms_mesh)),
                           "reorder": float(np.mean(ms_reorder)),
                           "halo_small128": engine.kernel_ms("halo_small"), "halo_small512": engine.kernel_ms("halo_small512"),
+                          "halo_small1024": engine.kernel_ms("halo_small1024"),
                           "halo_wave": engine.kernel_ms("halo_wave"), "halo_wg256": engine.kernel_ms("halo_wg256"),
                           "halo_wg1024": engine.kernel_ms("halo_wg1024"),
                           "pipe_build": engine.kernel_ms("pipe_build"), "pipe_stage_a": engine.kernel_ms("pipe_stage_a"),

@@ -35,6 +35,6 @@ for cfg in configs:
             pass   # (one class alone: the halos escalated to another class stay unfinished)
         ms.append([eng.kernel_ms(k) for k in ("halo", "halo_small", "halo_wave", "halo_wg256", "halo_wg1024", "halo_small512")])
     ms = np.array(ms[1:]).mean(axis=0)
-    print(f"{cfg:8s} halo {ms[0]:6.2f}  small {ms[1]:6.2f} / {ms[5]:6.2f}  wave {ms[2]:6.2f}  wg256 {ms[3]:6.2f}  wg1024 {ms[4]:6.2f}   n_small {int(eng.kernel_ms('n_small128'))} + {int(eng.kernel_ms('n_small512'))} esc {int(eng.kernel_ms('n_small_escalated'))} "
+    print(f"{cfg:8s} halo {ms[0]:6.2f}  small {ms[1]:6.2f} / {ms[5]:6.2f}  wave {ms[2]:6.2f}  wg256 {ms[3]:6.2f}  wg1024 {ms[4]:6.2f}   n_small {int(eng.kernel_ms('n_small128'))} + {int(eng.kernel_ms('n_small512'))} + {int(eng.kernel_ms('n_small1024'))} ({eng.kernel_ms('halo_small1024'):.2f} ms) esc {int(eng.kernel_ms('n_small_escalated'))} "
           f"n_wave {int(eng.kernel_ms('n_wave'))} n256 {int(eng.kernel_ms('n_wg256'))} n1024 {int(eng.kernel_ms('n_wg1024'))} passes {int(eng.kernel_ms('n_passes'))}", flush=True)
     eng.close()

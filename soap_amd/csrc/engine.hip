@@ -358,6 +358,7 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s);
 // the small-halo class (small_halo.hip): one wavefront per halo, slab in LDS; variants by slab entries and chunk content
 void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+void soap_launch_small_1024d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_128i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_512i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
@@ -542,6 +543,7 @@ struct TypeHost {
     }
 };
 
+#define NSV 3   // variants of the small-halo kernels
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
@@ -586,7 +588,7 @@ struct soap_engine {
         double ms = 0.0;
         long long nh = 0;
     } cls[3];
-    Class small[2];   // the small-halo class (no slab: its halos live in LDS), by slab entries: 128 (all of it in LDS), 512 (streamed columns in global memory)
+    Class small[NSV];   // the small-halo class (no slab: its halos live in LDS), by slab entries: 128 (all of it in LDS), 512 and 1024 (streamed columns in global memory)
     double *d_small_cols = nullptr;   // ... the latter's columns: seven per persistent wave
     int *d_small_esc = nullptr;       // [0] count, then the rows the small-halo kernels hand on to the wavefront class
     size_t small_esc_count = 0;
@@ -750,7 +752,7 @@ static int32_t create_resources(soap_engine *h) {
     }
     {
         // the small-halo class shares the priority level of the wavefront class
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < NSV; v++) {
             if (h->own_streams) HIPCHECK(hipStreamCreateWithPriority(&h->small[v].stream, hipStreamNonBlocking, prio_least));
             else HIPCHECK(hipStreamCreate(&h->small[v].stream));
             HIPCHECK(hipEventCreate(&h->small[v].done));
@@ -796,7 +798,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
         for (int q = 0; q < 2; q++) { if (h->cls[k].pstart[q]) (void)hipEventDestroy(h->cls[k].pstart[q]); if (h->cls[k].pdone[q]) (void)hipEventDestroy(h->cls[k].pdone[q]); }
         if (h->cls[k].stream) (void)hipStreamDestroy(h->cls[k].stream);
     }
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < NSV; v++) {
         if (h->small[v].d_queue) (void)hipFree(h->small[v].d_queue);
         if (h->small[v].d_todo) (void)hipFree(h->small[v].d_todo);
         if (h->small[v].done) (void)hipEventDestroy(h->small[v].done);
@@ -1284,8 +1286,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // particles (C3: 1.39 / 1.52 / 1.69 at the 10th / 50th / 90th percentile); one that does not fit after all comes back
     // with SOAP_HALO_FATAL_SLAB_OVERFLOW and is done by the wavefront class in the next pass.  Runs that need what the class
     // leaves out stay on the general path altogether.
-    std::vector<int> todo_small[2];
-    const long long small_ns[2] = {128, 512};
+    std::vector<int> todo_small[NSV];
+    const long long small_ns[NSV] = {128, 512, 1024};
     {
         bool small_ok = !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
                         P.profile != 1 && h->cfg.slab_capacity <= 0;
@@ -1306,21 +1308,27 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             double small_factor = 1.6;
             { const char *e = getenv("SOAP_ENGINE_SMALL_FACTOR"); if (e) small_factor = atof(e); }
             const bool use512 = !(getenv("SOAP_ENGINE_SMALL512") && atoi(getenv("SOAP_ENGINE_SMALL512")) == 0);
+            // The 1024-entry variant (25 KB of LDS and 256 registers per wave) is built and tested but NOT used by default: on C3 it
+            // takes 11 560 halos and halves the hand-overs (11 865 -> 6 404, clean-up launch 5.1 -> 3.7 ms), and the halo phase stays at
+            // 18.3 - 18.7 ms (rank of 8: 7.3 / 6.0 / 8.0 ms either way) -- the phase ends with the 256-thread class, not with the
+            // clean-up.  SOAP_ENGINE_SMALL1024=1 switches it on; it has no tensor pass.
+            const bool use1024 = !want_inertia && getenv("SOAP_ENGINE_SMALL1024") && atoi(getenv("SOAP_ENGINE_SMALL1024")) != 0;
             std::vector<int> rest;
             rest.reserve(todo[0].size());
             for (int i : todo[0]) {
                 const double pred = (double)h->h_nrbound[i] * small_factor + 4.0;
-                int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : -1);
-                if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry variant)
+                int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : (pred <= (double)small_ns[2] && use1024 ? 2 : -1));
+                if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry / the 1024-entry variant)
                 if (small_mode == 3) v = 1;
-                if (small_mode == 4 && v < 0) v = 1;   // (every halo of the class through the small-halo kernels: what does not fit is handed on)
+                if (small_mode == 5 && !want_inertia) v = 2;
+                if (small_mode == 4 && v < 0) v = use1024 ? 2 : 1;   // (every halo of the class through the small-halo kernels: what does not fit is handed on)
                 if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
             todo[0].swap(rest);
         }
     }
     static const bool small_handover = !(getenv("SOAP_ENGINE_SMALL_HANDOVER") && atoi(getenv("SOAP_ENGINE_SMALL_HANDOVER")) == 0);
-    if (small_handover && (!todo_small[0].empty() || !todo_small[1].empty())) {
+    if (small_handover && (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())) {
         // halos that outgrow the small-halo class are handed on inside the pass: list on the device, filled by its kernels
         if (h->small_esc_count < (size_t)h->n_halo + 1) {
             if (h->d_small_esc) (void)hipFree(h->d_small_esc);
@@ -1332,15 +1340,17 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemsetAsync(h->d_small_esc, 0, sizeof(int), st));
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
-    if (!todo_small[1].empty()) {
-        const size_t need = (size_t)(256 * 11) * 7 * (size_t)small_ns[1] * sizeof(double);
-        if (h->small_cols_bytes < need) {
+    if (!todo_small[1].empty() || !todo_small[2].empty()) {
+        // the streamed columns of the 512- and 1024-entry variants: a slice per persistent wave, one region per variant
+        const size_t need1 = (size_t)(256 * 11) * 7 * (size_t)small_ns[1] * sizeof(double), need2 = (size_t)(256 * 8) * 7 * (size_t)small_ns[2] * sizeof(double);
+        if (h->small_cols_bytes < need1 + need2) {
             if (h->d_small_cols) (void)hipFree(h->d_small_cols);
             h->d_small_cols = nullptr;
-            HIPCHECK(hipMalloc((void **)&h->d_small_cols, need));
-            h->small_cols_bytes = need;
+            HIPCHECK(hipMalloc((void **)&h->d_small_cols, need1 + need2));
+            h->small_cols_bytes = need1 + need2;
         }
         P.small_cols = h->d_small_cols;
+        P.small_cols2 = (double *)((char *)h->d_small_cols + need1);
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     TRACE("run: classified");
@@ -1393,9 +1403,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         return 0;
     };
-    int groups_small[2] = {256 * 11, 256 * 8};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight)
+    int groups_small[NSV] = {256 * 11, 256 * 8, 256 * 6};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight; the 1024-entry one 25 KB of LDS: six)
     if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
-    { const char *e = getenv("SOAP_ENGINE_GS"); if (e) groups_small[0] = groups_small[1] = atoi(e); }
+    { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
     { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
     auto launch_small = [&](int v, std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
         if (list.empty()) return 0;
@@ -1417,7 +1427,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             if (v == 0) soap_launch_small_128i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
             else soap_launch_small_512i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-        else soap_launch_small_512d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        else if (v == 1) soap_launch_small_512d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        else soap_launch_small_1024d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
@@ -1454,7 +1465,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(hipEventRecord(h->ev_p[0], st));
     TRACE("run: ev recorded");
     for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
-    for (int v = 0; v < 2; v++) { h->small[v].ms = 0.0; h->small[v].nh = 0; }
+    for (int v = 0; v < NSV; v++) { h->small[v].ms = 0.0; h->small[v].nh = 0; }
     h->n_small_escalated = 0;
     // Hybrid (SOAP_ENGINE_PIPELINE=1): the pipeline takes the halos of the wavefront class -- nine in ten, and what saturates the GPU on
     // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
@@ -1486,14 +1497,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // behind the small-halo kernels (and behind the wavefront class' own launch: same stream, same slab): the wavefront class once
     // more, for the rows that were handed on
     auto launch_cleanup = [&](bool join) -> int32_t {
-        if (P.small_esc == nullptr || (todo_small[0].empty() && todo_small[1].empty())) return 0;
+        if (P.small_esc == nullptr || (todo_small[0].empty() && todo_small[1].empty() && todo_small[2].empty())) return 0;
         soap_engine::Class &C = h->cls[0];
         hipStream_t cs = h->own_streams ? C.stream : h->cls[2].stream;
         int rc2 = alloc_slab(C, caps[0], groups[0]);
         if (rc2) return rc2;
-        for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(cs, h->small[v].done, 0));
+        for (int v = 0; v < NSV; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(cs, h->small[v].done, 0));
         HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
-        const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size()));
+        const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size() + todo_small[2].size()));
         if (C.nh == 0) HIPCHECK(hipEventRecord(C.start, cs));   // (no launch of the class' own in this run: its clock starts here)
         if (!want_inertia) soap_launch_halo_64n(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
         else soap_launch_halo_64i(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
@@ -1511,7 +1522,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // iteration's verdicts) they and the clean-up launch behind them were a serial tail of ~2.4 ms on an eighth of the C3 box
         static const bool small_late = getenv("SOAP_ENGINE_SMALL_LATE") && atoi(getenv("SOAP_ENGINE_SMALL_LATE")) != 0;
         if (!small_late && only_class < 0) {
-            for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev_p[0], false);
+            for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev_p[0], false);
             if (!rc) rc = launch_cleanup(false);
             if (rc) return rc;
             small_early = true;
@@ -1839,7 +1850,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         h->pool.release(d_state, n * 4); h->pool.release(d_rbuild, n * 8);
     }
     TRACE("run: single-kernel part");
-    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size());
+    h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size() + todo_small[2].size());
     std::vector<int> status(h->n_halo);
     double ms_total = 0.0;
     h->n_passes = 0;
@@ -1864,7 +1875,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     for (int pass = 0; pass < 12; pass++) {
         bool any = false;
         HIPCHECK(hipEventRecord(h->ev0, st));
-        if (only_class >= 0) { for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear(); if (only_class != 3) { todo_small[0].clear(); todo_small[1].clear(); } }   // diagnostics (3: the small-halo class)
+        if (only_class >= 0) { for (int k = 0; k < 3; k++) if (k != only_class) todo[k].clear(); if (only_class != 3) { todo_small[0].clear(); todo_small[1].clear(); todo_small[2].clear(); } }   // diagnostics (3: the small-halo class)
         for (int k = 0; k < 3; k++) any = any || !todo[k].empty();
         {
             // the thread-group classes first, largest groups first: a 1024-thread group needs an empty CU, and the waves of the
@@ -1872,16 +1883,16 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             static const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
             int rc = 0;
             const bool launch_small_now = !(small_early && pass == 0);   // (giants' mode: they started before the pipeline)
-            if (small_first && launch_small_now) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
+            if (small_first && launch_small_now) for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
             if (rc) return rc;
             rc = launch_single(todo, h->ev0, true);
             if (rc) return rc;
-            if (!small_first && launch_small_now) for (int v = 0; v < 2 && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
+            if (!small_first && launch_small_now) for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
             if (rc) return rc;
-            if (!launch_small_now) for (int v = 0; v < 2; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(st, h->small[v].done, 0));
-            for (int v = 0; v < 2; v++) any = any || !todo_small[v].empty();
+            if (!launch_small_now) for (int v = 0; v < NSV; v++) if (!todo_small[v].empty()) HIPCHECK(hipStreamWaitEvent(st, h->small[v].done, 0));
+            for (int v = 0; v < NSV; v++) any = any || !todo_small[v].empty();
             if (launch_small_now) { const int rc3 = launch_cleanup(true); if (rc3) return rc3; }
-            else if (P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) HIPCHECK(hipStreamWaitEvent(st, h->cls[0].done, 0));
+            else if (P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())) HIPCHECK(hipStreamWaitEvent(st, h->cls[0].done, 0));
         }
         if (pass == 0) {
             // the large halos launched before the pipeline stages: their statuses are checked with this pass
@@ -1898,7 +1909,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemcpyAsync(status.data(), h->d_status, (size_t)h->n_halo * 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         for (int k = 0; k < 3; k++) HIPCHECK(hipStreamSynchronize(h->cls[k].stream));
-        for (int v = 0; v < 2; v++) HIPCHECK(hipStreamSynchronize(h->small[v].stream));
+        for (int v = 0; v < NSV; v++) HIPCHECK(hipStreamSynchronize(h->small[v].stream));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(-101, std::string("halo kernel: ") + hipGetErrorString(le));
         float ms = 0;
@@ -1909,7 +1920,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // escalate halos whose search sphere did not fit their class' slab
         std::vector<int> next[3];
         bool grow_top = false;
-        if (pass == 0 && P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty())) {
+        if (pass == 0 && P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())) {
             int nesc = 0;
             HIPCHECK(hipMemcpy(&nesc, h->d_small_esc, sizeof(int), hipMemcpyDeviceToHost));
             h->n_small_escalated += nesc;
@@ -1933,7 +1944,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             float m2 = 0;
             if (todo[0].empty()) { (void)hipEventElapsedTime(&m2, h->cls[0].start, h->cls[0].done); h->cls[0].ms += m2; }
         }
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < NSV; v++) {
             if (todo_small[v].empty()) continue;
             float m2 = 0;
             (void)hipEventElapsedTime(&m2, h->small[v].start, h->small[v].done);
@@ -1975,7 +1986,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->cls[k].done, h->cls[k].stream));
             HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
         }
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < NSV; v++) {
             HIPCHECK(hipEventRecord(h->small[v].done, h->small[v].stream));
             HIPCHECK(hipStreamWaitEvent(st, h->small[v].done, 0));
         }
@@ -2078,7 +2089,9 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "halo_wg1024")) return h->cls[2].ms;
     if (!strcmp(name, "halo_small")) return h->small[0].ms;
     if (!strcmp(name, "halo_small512")) return h->small[1].ms;
-    if (!strcmp(name, "n_small")) return (double)(h->small[0].nh + h->small[1].nh);
+    if (!strcmp(name, "halo_small1024")) return h->small[2].ms;
+    if (!strcmp(name, "n_small1024")) return (double)h->small[2].nh;
+    if (!strcmp(name, "n_small")) return (double)(h->small[0].nh + h->small[1].nh + h->small[2].nh);
     if (!strcmp(name, "n_small128")) return (double)h->small[0].nh;
     if (!strcmp(name, "n_small512")) return (double)h->small[1].nh;
     if (!strcmp(name, "n_small_escalated")) return (double)h->n_small_escalated;

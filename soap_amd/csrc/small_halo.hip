@@ -1320,7 +1320,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
         g_W.L = P.boxsize; g_W.nu_density = P.nu_density; g_W.a = P.a; g_W.mpc = P.mpc; g_W.mpc20 = P.mpc20; g_W.G_eff = P.G_eff;
         g_W.hydro = P.hydro; g_W.has_nu = P.has_nu;
 #if SGLOBAL
-        g_W.cols = (GAS double *)P.small_cols + (long long)blockIdx.x * (SC_NCOLS * SNS);
+        g_W.cols = (GAS double *)(SNS > 512 ? P.small_cols2 : P.small_cols) + (long long)blockIdx.x * (SC_NCOLS * SNS);
 #endif
 #ifdef SMALL_CHECK
         g_W.dbg = (unsigned long long *)P.phase;
