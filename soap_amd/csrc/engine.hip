@@ -1537,7 +1537,18 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipMalloc((void **)&h->d_hdr, n * sizeof(HaloHdr)));
             h->hdr_bytes = n * sizeof(HaloHdr);
         }
-        long long *d_off, *d_est2; int *d_cap, *d_state; double *d_rbuild;
+        long long *d_off = nullptr, *d_est2 = nullptr; int *d_cap = nullptr, *d_state = nullptr; double *d_rbuild = nullptr;
+        // the scratch goes back to the pool however this block is left (every HIPCHECK below may return); on an error path the class
+        // streams are drained first, so that nothing in flight still reads it
+        struct PipeScratch {
+            soap_engine *h; size_t n; bool ok = false;
+            long long *&off, *&est2; int *&cap, *&state; double *&rbuild;
+            ~PipeScratch() {
+                if (!ok) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+                h->pool.release(off, n * 8); h->pool.release(est2, n * 8); h->pool.release(cap, n * 4);
+                h->pool.release(state, n * 4); h->pool.release(rbuild, n * 8);
+            }
+        } pipe_scratch{h, n, false, d_off, d_est2, d_cap, d_state, d_rbuild};
         HIPCHECK(h->pool.alloc((void **)&d_off, n * 8));
         HIPCHECK(h->pool.alloc((void **)&d_est2, n * 8));
         HIPCHECK(h->pool.alloc((void **)&d_cap, n * 4));
@@ -1846,8 +1857,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 if (props_iters & (1 << it)) { float m = 0; (void)hipEventElapsedTime(&m, h->ev_b[it][0], h->ev_b[it][1]); h->ms_stage_b += m; }
         }
         for (int k = 0; k < 3; k++) { single[k].insert(single[k].end(), todo[k].begin(), todo[k].end()); todo[k].swap(single[k]); }
-        h->pool.release(d_off, n * 8); h->pool.release(d_est2, n * 8); h->pool.release(d_cap, n * 4);
-        h->pool.release(d_state, n * 4); h->pool.release(d_rbuild, n * 8);
+        pipe_scratch.ok = true;   // (released by the guard)
     }
     TRACE("run: single-kernel part");
     h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size() + todo_small[2].size());
