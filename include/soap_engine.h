@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SOAP_ENGINE_ABI_VERSION 4
+#define SOAP_ENGINE_ABI_VERSION 5
 #define SOAP_STATS_COLUMNS 6 /* int64 per halo in the stats array of soap_engine_fetch */
 
 /* particle types the selections know about, in the reference's concatenation order
@@ -161,8 +161,14 @@ int32_t soap_engine_destroy(soap_engine *h);
  * Replaces share_array() + SharedMesh(comm, pos, resolution)
  * (chunk_tasks.py:165-170, :293-304; shared_mesh.py:11-114).
  *   type_slot      0..3  (PartType0,1,4,5)
- *   pos, vel       [n][3] doubles, as data[ptype]["Coordinates"/"Velocities"]
- *   mass           [n]    doubles  (Masses, or DynamicalMasses for PartType5)
+ *   pos            [n][3] doubles, as data[ptype]["Coordinates"]
+ *   vel            [n][3] data[ptype]["Velocities"], float64 or float32 (value_bytes = 8 or 4)
+ *   mass           [n]    Masses (DynamicalMasses for PartType5), the same width as vel
+ *   value_bytes    8 or 4: SWIFT snapshots hold Velocities and Masses in float32 and Coordinates in float64
+ *                  (tests/dummy_halo_generator.py:806-811); float32 values are widened on the device, on their way
+ *                  into the payload records, and every sum of the engine is fp64.  The reference keeps float32
+ *                  arrays float32 (its sums then round in float32, SO_properties.py:400-402): with float32 inputs
+ *                  the two agree to float32 rounding, not to 1e-10.
  *   grnr           [n]    GroupNr_bound, int32 or int64 (grnr_bytes = 4 or 8)
  *   fof            [n]    FOFGroupIDs int64
  *   resolution     mesh cells per dimension (chunk_tasks.py:299-302 computes it)
@@ -174,19 +180,28 @@ int32_t soap_engine_destroy(soap_engine *h);
  * made for the mesh build go back to the handle's allocation cache before it returns.
  */
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n,
-                                    const double *pos, const double *vel, const double *mass,
+                                    const double *pos, const void *vel, const void *mass, int32_t value_bytes,
                                     const void *grnr, int32_t grnr_bytes, const int64_t *fof,
                                     int32_t resolution, int32_t on_device);
+
+/*
+ * Device inputs (on_device == 1) are read on the engine's own HIP stream.  Call this before staging them with the
+ * stream (hipStream_t; NULL = the default stream) their producer ran on -- whatever wrote, converted or copied the
+ * arrays: the engine's stream is ordered behind everything submitted to that stream so far, with an event and
+ * without synchronising the host.  Host inputs need nothing of the kind.
+ */
+int32_t soap_engine_wait_stream(soap_engine *h, void *producer_stream);
 
 /*
  * Stage the chunk's neutrino particles (PartType6) and build their mesh.  They enter the spherical-overdensity
  * mass profile with mass * weight (weights may be negative) and feed NumberOfNeutrinoParticles /
  * RawNeutrinoMass / NoiseSuppressedNeutrinoMass and the neutrino terms of the concentration; nothing else
  * sees them (SO_properties.py:380-395, :507-511, :2689-2753).  All three arrays are consumed by the call (weighted and raw
- * masses go into the payload records).  n == 0 removes them.
+ * masses go into the payload records).  mass and weight are float64 or float32 (value_bytes = 8 or 4, as above).
+ * n == 0 removes them.
  */
-int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const double *mass,
-                                    const double *weight, int32_t resolution, int32_t on_device);
+int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const void *mass,
+                                    const void *weight, int32_t value_bytes, int32_t resolution, int32_t on_device);
 
 /*
  * Stage the chunk's halo table (halo_arrays of process_halos, halo_tasks.py:276-287),

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsoap_engine.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 NTYPES = 4
 
 
@@ -61,12 +61,13 @@ SYMBOLS = {
     "soap_engine_destroy": (C.c_int32, [C.c_void_p]),
     "soap_engine_stage_particles": (
         C.c_int32,
-        [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
          C.c_int32, C.c_void_p, C.c_int32, C.c_int32],
     ),
+    "soap_engine_wait_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "soap_engine_stage_neutrinos": (
         C.c_int32,
-        [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32],
+        [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32],
     ),  # fmt: skip
     "soap_engine_stage_halos": (
         C.c_int32,

@@ -70,7 +70,12 @@ def mask_cells(cell_size, dimension, centre, radius, done) -> np.ndarray:
         for sy, y in ((1, lo[:, 1]), (-1, hi[:, 1])):
             for sz, z in ((1, lo[:, 2]), (-1, hi[:, 2])):
                 np.add.at(diff, (x, y, z), sx * sy * sz)
-    cnt = diff.cumsum(0).cumsum(1).cumsum(2)[:-1, :-1, :-1]
+    # (in place: three int64 temporaries of the doubled grid otherwise; a cell is covered by at most len(centre) boxes)
+    if centre.shape[0] >= 2**31:
+        diff = diff.astype(np.int64)
+    for axis in range(3):
+        np.cumsum(diff, axis=axis, out=diff)
+    cnt = diff[:-1, :-1, :-1]
     d0, d1, d2 = dimension
     folded = cnt.reshape(2, d0, 2, d1, 2, d2).sum(axis=(0, 2, 4))
     return folded > 0
@@ -91,8 +96,9 @@ def resident_radius(mask: np.ndarray, cell_size, centre, read_radius, factor: fl
     dim = np.array(mask.shape)
     cs = np.broadcast_to(np.asarray(cell_size, dtype=np.float64), (3,))
     # number of cells NOT flagged in any box of the 3x tiled grid, from a summed-volume table
-    miss = np.tile(~mask, (3, 3, 3)).astype(np.int32)   # (27 x ncell < 2^31)
-    sv = np.zeros(tuple(3 * dim + 1), dtype=np.int32)
+    sv_dtype = np.int32 if 27 * mask.size < 2**31 else np.int64   # (the table's last entry counts up to 27 x ncell cells)
+    miss = np.tile(~mask, (3, 3, 3)).astype(sv_dtype)
+    sv = np.zeros(tuple(3 * dim + 1), dtype=sv_dtype)
     np.cumsum(miss, axis=0, out=miss)
     np.cumsum(miss, axis=1, out=miss)
     np.cumsum(miss, axis=2, out=sv[1:, 1:, 1:])

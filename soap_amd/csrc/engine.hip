@@ -257,8 +257,13 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
 // per particle.  Launched with the grid of k_cellid (same particles per block iteration).
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
                               const double *pos, double *x, double *y, double *z,
-                              Pay *pay, const double *vel, const double *mass, const int *g32, const long long *g64,
+                              Pay *pay, const void *vel_v, const void *mass_v, int value_bytes, const int *g32, const long long *g64,
                               const long long *fof, int nu) {
+    // Velocities / Masses arrive as float64 or as float32 (what SWIFT snapshots hold, tests/dummy_halo_generator.py:806-811):
+    // widened here, on the way into the payload record; every sum downstream is fp64
+    const double *vel = (const double *)vel_v, *mass = (const double *)mass_v;
+    const float *vel4 = (const float *)vel_v, *mass4 = (const float *)mass_v;
+    const bool narrow = value_bytes == 4;
     __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
@@ -317,10 +322,11 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
             // the payload record of the particle (read from the block's own window of the caller's arrays)
             Pay r;
             r.x = s_x[threadIdx.x]; r.y = s_y[threadIdx.x]; r.z = s_z[threadIdx.x];
-            r.m = mass[io];
-            if (nu) { r.vx = vel[io]; r.vy = 0.0; r.vz = 0.0; r.grnr = -1; r.fof = -1; }
+            r.m = narrow ? (double)mass4[io] : mass[io];
+            if (nu) { r.vx = narrow ? (double)vel4[io] : vel[io]; r.vy = 0.0; r.vz = 0.0; r.grnr = -1; r.fof = -1; }
             else {
-                r.vx = vel[3 * (long long)io]; r.vy = vel[3 * (long long)io + 1]; r.vz = vel[3 * (long long)io + 2];
+                const long long v0 = 3 * (long long)io;
+                r.vx = narrow ? (double)vel4[v0] : vel[v0]; r.vy = narrow ? (double)vel4[v0 + 1] : vel[v0 + 1]; r.vz = narrow ? (double)vel4[v0 + 2] : vel[v0 + 2];
                 r.grnr = g64 ? g64[io] : (long long)g32[io];
                 r.fof = fof[io];
             }
@@ -454,6 +460,201 @@ __global__ void k_estimate(const RunParams *Pp, long long *est, const double *rb
     if (lane == 0) est[h] = tot;
 }
 
+// ---- Where will the radius loop of a halo end?  (scheduling only: no result depends on it) -------------------------
+// The loop of halo_tasks.py:74-187 grows the search sphere x1.2 per round until the enclosed density of particle types
+// 0, 1, 4, 5 has dropped below the run's target density and every calculation has the radius it asks for (an SO beyond its
+// own radius, a radius multiple beyond  multiple x parent, the flow-rate shells 1.05 R_SO, apertures their physical radius).
+// For most halos that is a round or three beyond the catalogue's search radius and the default first superset
+// (first_factor x search radius) holds it.  A small central inside the envelope of a massive neighbour is different: the
+// density about it stays above the target until the sphere has grown to the neighbour's own overdensity radius -- tens of
+// rounds, a sphere of 1e5 particles for a halo of 50 -- and the work estimate of its first sphere says nothing about
+// that.  This kernel runs the loop on a THINNED copy of the particles: every PRED_STRIDE-th particle of the cell-ordered
+// coordinates (the order inside a mesh cell is the order the snapshot was written in, unrelated to position), weighted
+// with the mean particle mass of its type, binned on the ladder R_k = search_radius x 1.2^k by one wave per halo.
+// Out: the radius the first sorted superset should reach (0: the default) -- so that the sphere is selected and sorted once
+// instead of shell by shell, the halo is sent to the thread-group class of its FINAL size, and the longest chains of a
+// class start first.  A wrong guess costs time, never correctness: the halo kernels extend a superset that is too small
+// and ignore what they do not need of one that is too large.
+#define PRED_K 64          // ladder steps (1.2^63 ~ 1e5 search radii: never the limit)
+#define PRED_MAXS 4096     // thinned particles per sphere and type at most (a sphere of 4e6 candidates is thinned further)
+// the mesh rows (k, j, x-run) a sphere of radius R about halo h overlaps in the mesh of type T (shared_mesh.py:146-179, as k_estimate)
+struct PredRows {
+    Mask256 mk[3];
+    int run_lo[4], run_hi[4], nrun, nk, nj, ntrip, res;
+    __device__ __forceinline__ void build(const RunParams &P, const TypeDev &T, long long h, double R) {
+        const double L = P.boxsize;
+        mk[0] = Mask256(); mk[1] = Mask256(); mk[2] = Mask256();
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double c = P.halo.cofp[3 * h + d];
+            int min_copy = 0, max_copy = 0, guard = 0;
+            while (c + (double)(min_copy - 1) * L + R >= T.pos_min[d] && guard++ < 64) min_copy--;
+            guard = 0;
+            while (c + (double)(max_copy + 1) * L - R <= T.pos_max[d] && guard++ < 64) max_copy++;
+            for (int cp = min_copy; cp <= max_copy; cp++) {
+                const double lo = fmax(T.pos_min[d], c + (double)cp * L - R), hi = fmin(T.pos_max[d], c + (double)cp * L + R);
+                const double qlo = floor((lo - T.pos_min[d]) / T.cell_size[d]), qhi = floor((hi - T.pos_min[d]) / T.cell_size[d]);
+                const int ilo = qlo < 0.0 ? 0 : (qlo > 1e9 ? 1000000000 : (int)qlo);
+                const int ihi = qhi < -1.0 ? -1 : (qhi > (double)(T.res - 1) ? T.res - 1 : (int)qhi);
+                if (ilo <= ihi) mk[d].set_range(ilo, ihi);
+            }
+        }
+        res = T.res;
+        nrun = 0;
+        for (int i0 = 0; i0 < res && nrun < 4;) {
+            if (!mk[0].get(i0)) { i0++; continue; }
+            int i1 = i0;
+            while (i1 + 1 < res && mk[0].get(i1 + 1)) i1++;
+            run_lo[nrun] = i0; run_hi[nrun] = i1; nrun++;
+            i0 = i1 + 1;
+        }
+        nk = mk[2].count(); nj = mk[1].count();
+        ntrip = nk * nj * nrun;
+    }
+    // first and one-past-last cell-ordered particle of row number tl
+    __device__ __forceinline__ void row(const TypeDev &T, int tl, unsigned &beg, unsigned &end) const {
+        const int rr = tl % nrun, pj = (tl / nrun) % nj, pk = tl / (nrun * nj);
+        const int k = mk[2].nth(pk), j = mk[1].nth(pj);
+        const long long rowbase = (long long)res * j + (long long)res * res * k;
+        int rl = run_lo[0], rh = run_hi[0];
+        if (rr == 1) { rl = run_lo[1]; rh = run_hi[1]; } else if (rr == 2) { rl = run_lo[2]; rh = run_hi[2]; } else if (rr == 3) { rl = run_lo[3]; rh = run_hi[3]; }
+        beg = T.cell_offset[rowbase + rl];
+        end = T.cell_offset[rowbase + rh + 1];
+    }
+};
+// particles in the mesh cells a sphere of radius R about halo h overlaps, all staged types (what k_estimate counts); wave total
+__device__ __forceinline__ long long pred_candidates(const RunParams &P, long long h, double R, int lane) {
+    long long tot = 0;
+    for (int ts = 0; ts < NT_ALL; ts++) {
+        const TypeDev &T = P.t[ts];
+        if (T.n == 0) continue;
+        PredRows rows;
+        rows.build(P, T, h, R);
+        for (int tl = lane; tl < rows.ntrip; tl += 64) { unsigned beg, end; rows.row(T, tl, beg, end); tot += (long long)(end - beg); }
+    }
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    return tot;
+}
+__global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_first, long long *est, int stride, int min_samples, double margin) {
+    __shared__ float s_bin[BLK / 64][PRED_K];
+    __shared__ double s_dens[BLK / 64][PRED_K];
+    const RunParams &P = *Pp;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long h = blockIdx.x * (long long)(BLK / 64) + wv;
+    if (h >= P.halo.n) return;
+    float *bin = s_bin[wv];
+    double *dens = s_dens[wv];
+    const double Rs = P.halo.search_radius[h], Rread = P.halo.read_radius[h];
+    const double cap = fmin(0.5 * P.boxsize, fmax(Rread, P.halo.resident ? P.halo.resident[h] : 0.0));
+    const double R0 = fmin(Rread, Rs * P.first_factor);
+    double out = 0.0;
+    long long cand0 = -1;
+    const bool central = P.halo.is_central[h] == 1 && P.target_density > 0.0;
+    if (central && cap > R0 * 1.0001) {
+        const double cx = P.halo.cofp[3 * h], cy = P.halo.cofp[3 * h + 1], cz = P.halo.cofp[3 * h + 2], L = P.boxsize;
+        const double inv_log = 1.0 / log2(1.2);
+        bin[lane] = 0.0f;
+        double Rlo = -1.0, Rhi = R0, need = 0.0;
+        float nsamp = 0.0f;
+        for (int iter = 0; iter < 8; iter++) {
+            // ---- thinned particles of the shell Rlo < r <= Rhi into the ladder bins: the mesh rows of the sphere one after
+            // the other (their cell_offset lookups 64 at a time, lanes = rows), lanes = the row's thinned particles
+            const double R2lo = Rlo < 0.0 ? -1.0 : Rlo * Rlo, R2hi = Rhi * Rhi;
+            long long cand = 0;
+            for (int ts = 0; ts < NT_ALL; ts++) {
+                const TypeDev &T = P.t[ts];
+                if (T.n == 0) continue;
+                PredRows rows;
+                rows.build(P, T, h, Rhi);
+                // candidates of this type (the work estimate of the first sphere comes for free), and how far to thin them
+                long long tot = 0;
+                for (int tl = lane; tl < rows.ntrip; tl += 64) { unsigned beg, end; rows.row(T, tl, beg, end); tot += (long long)(end - beg); }
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                cand += tot;
+                if (ts >= SOAP_NTYPES) continue;   // (neutrinos: counted as candidates, no part of the density test)
+                unsigned st = (unsigned)stride;
+                while ((long long)st * PRED_MAXS < tot) st <<= 1;
+                const float w = (float)(T.mean_mass * (double)st);
+                for (int t0 = 0; t0 < rows.ntrip; t0 += 64) {
+                    unsigned mybeg = 0, myend = 0;
+                    if (t0 + lane < rows.ntrip) rows.row(T, t0 + lane, mybeg, myend);
+                    const int cnt = rows.ntrip - t0 < 64 ? rows.ntrip - t0 : 64;
+                    for (int q = 0; q < cnt; q++) {
+                        const unsigned beg = (unsigned)__builtin_amdgcn_readlane((int)mybeg, q), end = (unsigned)__builtin_amdgcn_readlane((int)myend, q);
+                        const unsigned p0 = ((beg + st - 1u) / st) * st;
+                        for (unsigned pb = p0; pb < end; pb += 64u * st) {
+                            const unsigned p = pb + (unsigned)lane * st;
+                            if (p < end) {
+                                const double ax = min_image(T.x[p], cx, L), ay = min_image(T.y[p], cy, L), az = min_image(T.z[p], cz, L);
+                                const double r2 = (ax * ax + ay * ay) + az * az;
+                                if (r2 <= R2hi && r2 > R2lo) {
+                                    // smallest k with r <= Rs 1.2^k
+                                    int kb = r2 > Rs * Rs ? (int)ceil(0.5 * log2(r2 / (Rs * Rs)) * inv_log) : 0;
+                                    kb = kb < 0 ? 0 : (kb > PRED_K - 1 ? PRED_K - 1 : kb);
+                                    atomicAdd(&bin[kb], w);
+                                    nsamp += 1.0f;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (iter == 0) cand0 = cand;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- the loop on the ladder: lane k holds step k
+            const double Rk = Rs * exp2((double)lane * log2(1.2));
+            double M = (double)bin[lane];
+            for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(M, o, 64); if (lane >= o) M += v; }
+            const bool known = Rk <= Rhi * 1.000001;      // steps the thinned sphere covers
+            dens[lane] = known ? M / (4.0 / 3.0 * M_PI * Rk * Rk * Rk) : 1e300;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (iter == 0) {
+                // the enclosed density at the end of the default first superset: not above the target (any halo that is not
+                // inside a larger one's envelope) means the loop ends inside it -- nothing to guess
+                int klast = 0;
+                for (int k = 0; k < PRED_K; k++) if (dens[k] < 1e299) klast = k;
+                if (dens[klast] <= P.target_density) break;
+            }
+            // lanes = calculations: the radius each one asks for (1e300: its density is not reached inside Rhi)
+            double want = 0.0, Rso = 0.0;
+            {
+                const int c = lane;
+                soap_calc_desc cd = P.calcs[c < P.ncalc ? c : 0];
+                const bool live = c >= 1 && c < P.ncalc;
+                double rho = 0.0;
+                if (c == 0) rho = P.target_density;                   // (lane 0: the loop's own density test)
+                else if (live && cd.kind == SOAP_CALC_SO_DENSITY) rho = cd.reference_density;
+                if (rho > 0.0) {
+                    Rso = 1e300;
+                    for (int k = 0; k < PRED_K; k++) {
+                        if (dens[k] <= rho) { Rso = Rs * exp2((double)k * log2(1.2)); break; }
+                        if (dens[k] > 1e299) break;
+                    }
+                    want = Rso;
+                    if (c >= 1 && (cd.flags & SOAP_CALC_FLAG_DM_FLOW) && Rso < 1e299) want = 1.05 * Rso;
+                }
+                const int par = (live && cd.kind == SOAP_CALC_SO_MULTIPLE) ? cd.parent : 0;
+                const double Rpar = __shfl(Rso, par, 64);
+                if (live && cd.kind == SOAP_CALC_SO_MULTIPLE) want = Rpar < 1e299 ? cd.radius * Rpar : 1e300;
+                if (live && cd.kind != SOAP_CALC_SO_DENSITY && cd.kind != SOAP_CALC_SO_MULTIPLE) want = cd.physical_radius_mpc;
+            }
+            for (int o = 32; o > 0; o >>= 1) want = fmax(want, __shfl_xor(want, o, 64));
+            need = want;
+            if (need <= Rhi) break;                 // the thinned sphere holds the end of the loop
+            if (Rhi >= cap) { need = cap; break; }  // as far as the resident region goes
+            Rlo = Rhi;
+            Rhi = fmin(cap, fmax(2.0 * Rhi, need < 1e299 ? 1.1 * need : 0.0));
+        }
+        float ns = nsamp;
+        for (int o = 32; o > 0; o >>= 1) ns += __shfl_xor(ns, o, 64);
+        // a guess from a handful of thinned particles is noise: such a halo keeps the default (it is small, whatever it does)
+        if (ns >= (float)min_samples && need * margin > R0) out = fmin(cap, need * margin);
+    }
+    // the work estimate: candidates of the first sorted superset
+    long long e = out > 0.0 ? pred_candidates(P, h, out, lane) : (cand0 >= 0 ? cand0 : pred_candidates(P, h, R0, lane));
+    if (lane == 0) { r_first[h] = out; est[h] = e; }
+}
+
 // brute-force membership list for verification (same arithmetic as the property kernels)
 __global__ void k_membership(TypeDev T, double cx, double cy, double cz, double L, double R,
                              int strict, int bound_only, long long hindex, unsigned *count,
@@ -532,6 +733,7 @@ struct TypeHost {
     unsigned *orig = nullptr, *cell_offset = nullptr;
     Pay *pay = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
+    double mean_mass = 0.0;
     void release(DevPool &pool) {
         pool.release(pay, (size_t)n * sizeof(Pay));
         void *d8[] = {x, y, z};
@@ -544,6 +746,8 @@ struct TypeHost {
 };
 
 #define NSV 3   // variants of the small-halo kernels
+#define SMALL_MAXG512 (256 * 11)    // most persistent waves of the 512- / 1024-entry variants (slices of the streamed-column buffer)
+#define SMALL_MAXG1024 (256 * 8)
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
@@ -556,6 +760,10 @@ struct soap_engine {
     long long *d_index = nullptr, *d_nrbound = nullptr, *d_stats = nullptr;
     int *d_central = nullptr, *d_status = nullptr, *d_todo = nullptr;
     double *d_resident = nullptr;
+    double *d_first = nullptr;    // radius the first superset of every halo should reach (k_predict), n_halo doubles
+    size_t first_count = 0;
+    std::vector<double> h_first;
+    long long n_predicted = 0;    // halos whose guess lies beyond the default first superset
     // member probe
     long long probe_row = -1, probe_cap = 0;
     int probe_calc = 0;
@@ -618,7 +826,7 @@ struct soap_engine {
     long long n_pipeline = 0, n_single = 0, n_small_escalated = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
 };
 
 static void free_slab(soap_engine::Class &c) {
@@ -727,6 +935,7 @@ static int32_t create_resources(soap_engine *h) {
     HIPCHECK(hipStreamCreate(&h->stream));
     HIPCHECK(hipEventCreate(&h->ev0));
     HIPCHECK(hipEventCreate(&h->ev1));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIPCHECK(hipMalloc((void **)&h->d_queue, sizeof(unsigned)));
     // one stream per thread-group class, on distinct priority levels where the device offers three:
     // streams of equal priority may be mapped onto the same hardware queue (and then serialise), streams of
@@ -785,11 +994,18 @@ static void free_halos(soap_engine *h) {
 int32_t soap_engine_destroy(soap_engine *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
+    const bool trace = getenv("SOAP_ENGINE_TRACE") != nullptr;
+    auto probe = [&](const char *tag) { const hipError_t e = hipGetLastError(); if (e != hipSuccess && trace) { fprintf(stderr, "[soap_engine] destroy: %s left %s\n", tag, hipGetErrorString(e)); fflush(stderr); } };
+    probe("before");
     (void)hipStreamSynchronize(h->stream);
+    probe("sync");
     for (int t = 0; t < NT_ALL; t++) h->t[t].release(h->pool);
+    probe("types");
     free_halos(h);
     h->pool.purge();
+    probe("purge");
     free_slabs(h);
+    probe("slabs");
     for (int k = 0; k < 3; k++) {
         if (h->cls[k].d_queue) (void)hipFree(h->cls[k].d_queue);
         if (h->cls[k].d_todo) (void)hipFree(h->cls[k].d_todo);
@@ -805,8 +1021,11 @@ int32_t soap_engine_destroy(soap_engine *h) {
         if (h->small[v].start) (void)hipEventDestroy(h->small[v].start);
         if (h->small[v].stream) (void)hipStreamDestroy(h->small[v].stream);
     }
+    probe("class resources");
+    if (h->d_first) (void)hipFree(h->d_first);
     if (h->d_small_cols) (void)hipFree(h->d_small_cols);
     if (h->d_small_esc) (void)hipFree(h->d_small_esc);
+    probe("small");
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_calcs) (void)hipFree(h->d_calcs);
     if (h->d_coloff) (void)hipFree(h->d_coloff);
@@ -823,49 +1042,79 @@ int32_t soap_engine_destroy(soap_engine *h) {
     for (int k = 0; k < 6; k++) if (h->ev_p[k]) (void)hipEventDestroy(h->ev_p[k]);
     if (h->d_probe) (void)hipFree(h->d_probe);
     if (h->d_probe_count) (void)hipFree(h->d_probe_count);
+    probe("tables");
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    probe("events");
     delete h;
     return 0;
 }
 
+// sum of every 64th mass (the mean particle mass of the type, for k_predict)
+__global__ void k_mass_sample(const void *mass, int value_bytes, long long n, double *partial /*[grid]*/) {
+    double s = 0.0;
+    for (long long i = (blockIdx.x * (long long)BLK + threadIdx.x) * 64; i < n; i += (long long)gridDim.x * BLK * 64)
+        s += value_bytes == 4 ? (double)((const float *)mass)[i] : ((const double *)mass)[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double w[BLK / 64];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < BLK / 64; k++) t += w[k]; partial[blockIdx.x] = t; }
+}
+__global__ void k_widen(const float *in, long long n, double *out) {
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) out[i] = (double)in[i];
+}
 // weighted neutrino masses  m_eff = mass * weight  (SO_properties.py:381-383)
-__global__ void k_weighted_mass(const double *mass, const double *weight, long long n, double *out) {
+__global__ void k_weighted_mass(const void *mass, const void *weight, int value_bytes, long long n, double *out) {
     for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK)
-        out[i] = mass[i] * weight[i];
+        out[i] = value_bytes == 4 ? (double)((const float *)mass)[i] * (double)((const float *)weight)[i]
+                                  : ((const double *)mass)[i] * ((const double *)weight)[i];
 }
 
-static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const double *vel,
-                          const double *mass, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
+static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const void *vel,
+                          const void *mass, int32_t value_bytes, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
                           int32_t resolution, int32_t on_device);
 
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t ts, int64_t n, const double *pos,
-                                    const double *vel, const double *mass, const void *grnr,
+                                    const void *vel, const void *mass, int32_t value_bytes, const void *grnr,
                                     int32_t grnr_bytes, const int64_t *fof, int32_t resolution,
                                     int32_t on_device) {
     if (!h) return fail(-1, "null handle");
     if (ts < 0 || ts >= SOAP_NTYPES) return fail(-2, "type_slot out of range");
     if (n > 0 && (!vel || !grnr || !fof)) return fail(-6, "null particle array");
-    return stage_type(h, ts, n, pos, vel, mass, grnr, grnr_bytes, fof, resolution, on_device);
+    return stage_type(h, ts, n, pos, vel, mass, value_bytes, grnr, grnr_bytes, fof, resolution, on_device);
 }
 
-int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const double *mass,
-                                    const double *weight, int32_t resolution, int32_t on_device) {
+int32_t soap_engine_stage_neutrinos(soap_engine *h, int64_t n, const double *pos, const void *mass,
+                                    const void *weight, int32_t value_bytes, int32_t resolution, int32_t on_device) {
     if (!h) return fail(-1, "null handle");
     if (n > 0 && !weight) return fail(-6, "null particle array");
-    // the weights ride in the `vel` argument (3 doubles per particle are not needed: one is), ids are absent
-    return stage_type(h, NU_SLOT, n, pos, weight, mass, nullptr, 4, nullptr, resolution, on_device);
+    // the weights ride in the `vel` argument (3 values per particle are not needed: one is), ids are absent
+    return stage_type(h, NU_SLOT, n, pos, weight, mass, value_bytes, nullptr, 4, nullptr, resolution, on_device);
 }
 
-static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const double *vel,
-                          const double *mass, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
+int32_t soap_engine_wait_stream(soap_engine *h, void *producer_stream) {
+    if (!h) return fail(-1, "null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    // everything submitted to the caller's stream so far (the kernels that produced, widened or copied the device arrays the
+    // next stage_* call reads) is ordered in front of the engine's own work: an event, no host synchronisation
+    HIPCHECK(hipEventRecord(h->ev_in, (hipStream_t)producer_stream));
+    HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_in, 0));
+    return 0;
+}
+
+static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *pos, const void *vel,
+                          const void *mass, int32_t value_bytes, const void *grnr, int32_t grnr_bytes, const int64_t *fof,
                           int32_t resolution, int32_t on_device) {
     const bool nu = ts == NU_SLOT;
     if (n < 0 || n >= (1ll << PIDX_BITS)) return fail(-3, "particle count per type must be < 2^29");
     if (grnr_bytes != 4 && grnr_bytes != 8) return fail(-4, "grnr_bytes must be 4 or 8");
+    if (value_bytes != 4 && value_bytes != 8) return fail(-4, "value_bytes (Velocities / Masses / Weights) must be 4 or 8");
     if (resolution < 1 || resolution > 256) return fail(-5, "mesh resolution must be in [1,256]");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    (void)hipGetLastError();   // (a stale error of an earlier, unrelated call is not this call's failure)
     DevPool &pool = h->pool;
     h->t[ts].release(pool);
     if (n == 0) return 0;   // SharedMesh.empty (shared_mesh.py:25-27)
@@ -884,25 +1133,26 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         return e;
     };
     auto body = [&]() -> int32_t {
-        const double *dpos = pos, *dvel = vel, *dmass = mass;
+        const double *dpos = pos;
+        const void *dvel = vel, *dmass = mass;
         const void *dgr = grnr;
         const long long *dfof = (const long long *)fof;
         if (!on_device) {
-            const size_t vbytes = (size_t)n * (nu ? 8 : 24);   // neutrinos: one weight per particle in place of a velocity
+            const size_t vbytes = (size_t)n * (nu ? 1 : 3) * (size_t)value_bytes;   // neutrinos: one weight per particle in place of a velocity
             void *a, *b, *c, *d = nullptr, *e = nullptr;
             HIPCHECK(grab(&a, (size_t)n * 24, inputs));
             HIPCHECK(grab(&b, vbytes, inputs));
-            HIPCHECK(grab(&c, (size_t)n * 8, inputs));
+            HIPCHECK(grab(&c, (size_t)n * value_bytes, inputs));
             HIPCHECK(hipMemcpyAsync(a, pos, (size_t)n * 24, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(b, vel, vbytes, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(c, mass, (size_t)n * value_bytes, hipMemcpyHostToDevice, st));
             if (!nu) {
                 HIPCHECK(grab(&d, (size_t)n * grnr_bytes, inputs));
                 HIPCHECK(grab(&e, (size_t)n * 8, inputs));
                 HIPCHECK(hipMemcpyAsync(d, grnr, (size_t)n * grnr_bytes, hipMemcpyHostToDevice, st));
                 HIPCHECK(hipMemcpyAsync(e, fof, (size_t)n * 8, hipMemcpyHostToDevice, st));
             }
-            dpos = (const double *)a; dvel = (const double *)b; dmass = (const double *)c;
+            dpos = (const double *)a; dvel = b; dmass = c;
             dgr = d; dfof = (const long long *)e;
         }
         HIPCHECK(hipEventRecord(h->ev0, st));
@@ -913,7 +1163,14 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         hipLaunchKernelGGL(k_minmax, dim3(gmm), dim3(BLK), 0, st, dpos, (long long)n, d_partial);
         std::vector<double> part(gmm * 6);
         HIPCHECK(hipMemcpyAsync(part.data(), d_partial, gmm * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+        const int gms = 64;
+        double *d_msum;
+        std::vector<double> msum(gms);
+        HIPCHECK(grab((void **)&d_msum, gms * sizeof(double), scratch));
+        hipLaunchKernelGGL(k_mass_sample, dim3(gms), dim3(BLK), 0, st, dmass, (int)value_bytes, (long long)n, d_msum);
+        HIPCHECK(hipMemcpyAsync(msum.data(), d_msum, gms * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
+        { double t = 0.0; for (double v : msum) t += v; T.mean_mass = t / (double)((n + 63) / 64); }
         for (int d = 0; d < 3; d++) { T.pos_min[d] = INFINITY; T.pos_max[d] = -INFINITY; }
         for (int b = 0; b < gmm; b++)
             for (int d = 0; d < 3; d++) {
@@ -953,7 +1210,8 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         for (double **p : dp) HIPCHECK(pool.alloc((void **)p, (size_t)n * 8));
         // (velocities, masses and ids are only read by the placement pass below, which copies them into the payload records:
         // the pointers live in locals, nothing of the caller's -- or of the device copies of host inputs -- is kept)
-        const double *t_vel = dvel, *t_mass = dmass;
+        const void *t_vel = dvel, *t_mass = dmass;
+        int t_vbytes = value_bytes;
         const long long *t_fof = dfof, *t_g64 = T.grnr64 ? (const long long *)dgr : nullptr;
         const int *t_g32 = T.grnr64 ? nullptr : (const int *)dgr;
         if (nu) {
@@ -961,15 +1219,23 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
             double *meff;
             HIPCHECK(pool.alloc((void **)&meff, (size_t)n * 8));
             scratch.push_back({meff, (size_t)n * 8});
-            hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (long long)n, meff);
-            t_vel = dmass;
+            hipLaunchKernelGGL(k_weighted_mass, dim3(grid), dim3(BLK), 0, st, dmass, dvel, (int)value_bytes, (long long)n, meff);
+            if (value_bytes == 4) {
+                // the raw masses ride in the velocity slot of the record next to the fp64 weighted ones: widen them too
+                double *raw;
+                HIPCHECK(pool.alloc((void **)&raw, (size_t)n * 8));
+                scratch.push_back({raw, (size_t)n * 8});
+                hipLaunchKernelGGL(k_widen, dim3(grid), dim3(BLK), 0, st, (const float *)dmass, (long long)n, raw);
+                t_vel = raw;
+            } else t_vel = dmass;
             t_mass = meff;
+            t_vbytes = 8;
             t_g32 = nullptr; t_g64 = nullptr; t_fof = nullptr;
         }
         HIPCHECK(hipEventCreate(&ev2));
         HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
         hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
-                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_g32, t_g64, t_fof, nu ? 1 : 0);
+                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0);
         HIPCHECK(hipEventRecord(ev2, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -1155,6 +1421,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         D.x = T.x; D.y = T.y; D.z = T.z; D.vel = T.vel; D.mass = T.mass;
         D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset; D.pay = T.pay;
         for (int d = 0; d < 3; d++) { D.pos_min[d] = T.pos_min[d]; D.pos_max[d] = T.pos_max[d]; D.cell_size[d] = T.cell_size[d]; }
+        D.mean_mass = T.mean_mass;
         if (t < SOAP_NTYPES) P.soft[t] = h->cfg.softening[t];
     }
     P.halo.n = h->n_halo; P.halo.cofp = h->d_cofp; P.halo.search_radius = h->d_search; P.halo.read_radius = h->d_read;
@@ -1219,12 +1486,44 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     std::vector<long long> est(h->n_halo);
     const auto t_host0b = std::chrono::steady_clock::now();
     {
+        // where each halo's radius loop is expected to end (k_predict), then the candidates of the first superset out to there:
+        // the work estimate the classes, the launch order and the slab sizes go by
+        int pred = (P.literal || h->cfg.slab_capacity > 0) ? 0 : 1;
+        { const char *e = getenv("SOAP_ENGINE_PREDICT"); if (e) pred = atoi(e); }
+        if (h->first_count < (size_t)h->n_halo) {
+            if (h->d_first) (void)hipFree(h->d_first);
+            h->d_first = nullptr;
+            h->first_count = (size_t)h->n_halo + (size_t)h->n_halo / 4;
+            HIPCHECK(hipMalloc((void **)&h->d_first, h->first_count * sizeof(double)));
+        }
+        h->h_first.assign((size_t)h->n_halo, 0.0);
+        h->n_predicted = 0;
+        int pred_stride = 64, pred_min = 32;
+        double pred_margin = 1.0;
+        if (pred) {
+            long long ntot4 = 0;
+            for (int t = 0; t < SOAP_NTYPES; t++) ntot4 += h->t[t].n;
+            pred_stride = (int)std::min<long long>(64, std::max<long long>(1, ntot4 / 262144));
+            { const char *e = getenv("SOAP_ENGINE_PRED_STRIDE"); if (e) pred_stride = std::max(1, atoi(e)); }
+            { const char *e = getenv("SOAP_ENGINE_PRED_MIN"); if (e) pred_min = atoi(e); }
+            { const char *e = getenv("SOAP_ENGINE_PRED_MARGIN"); if (e) pred_margin = atof(e); }
+            P.halo.first_radius = h->d_first;
+        }
         long long *d_est;
         HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
-        hipLaunchKernelGGL(k_estimate, dim3((unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
+        const unsigned gw = (unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64));
+        if (pred) {
+            hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_stride, pred_min, pred_margin);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipMemcpyAsync(h->h_first.data(), h->d_first, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));   // (first_radius set)
+        } else {
+            hipLaunchKernelGGL(k_estimate, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
+        }
         HIPCHECK(hipMemcpyAsync(est.data(), d_est, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         h->pool.release(d_est, (size_t)h->n_halo * 8);
+        for (double v : h->h_first) h->n_predicted += v > 0.0;
     }
     TRACE("run: estimate done");
     // ---- class limits follow the load.  A halo is a serial chain on ONE thread group: ~4e-7 s per candidate on a
@@ -1242,7 +1541,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                               !(getenv("SOAP_ENGINE_LOAD_CLASSES") && atoi(getenv("SOAP_ENGINE_LOAD_CLASSES")) == 0);
     if (load_classes) {
         nb_small = std::min<long long>(nb_small, std::max<long long>(2048, (long long)(run_tau / 4.0e-7)));
-        static const double medium_cost = getenv("SOAP_ENGINE_MEDIUM_COST") ? atof(getenv("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
+        const double medium_cost = getenv("SOAP_ENGINE_MEDIUM_COST") ? atof(getenv("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
         nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / medium_cost)));
     }
     const auto t_host1 = std::chrono::steady_clock::now();
@@ -1327,7 +1626,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             todo[0].swap(rest);
         }
     }
-    static const bool small_handover = !(getenv("SOAP_ENGINE_SMALL_HANDOVER") && atoi(getenv("SOAP_ENGINE_SMALL_HANDOVER")) == 0);
+    // (diagnostic switches are read on every run, like SOAP_ENGINE_SMALL above: a sweep that toggles them inside one process measures what it says)
+    const bool small_handover = !(getenv("SOAP_ENGINE_SMALL_HANDOVER") && atoi(getenv("SOAP_ENGINE_SMALL_HANDOVER")) == 0);
     if (small_handover && (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())) {
         // halos that outgrow the small-halo class are handed on inside the pass: list on the device, filled by its kernels
         if (h->small_esc_count < (size_t)h->n_halo + 1) {
@@ -1342,7 +1642,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     }
     if (!todo_small[1].empty() || !todo_small[2].empty()) {
         // the streamed columns of the 512- and 1024-entry variants: a slice per persistent wave, one region per variant
-        const size_t need1 = (size_t)(256 * 11) * 7 * (size_t)small_ns[1] * sizeof(double), need2 = (size_t)(256 * 8) * 7 * (size_t)small_ns[2] * sizeof(double);
+        // (sized for the largest grids launch_small may use, SMALL_MAXG512 / SMALL_MAXG1024 waves; the region of the 1024-entry
+        // variant -- 117 MB -- only when that variant has work)
+        const size_t need1 = (size_t)SMALL_MAXG512 * 7 * (size_t)small_ns[1] * sizeof(double);
+        const size_t need2 = todo_small[2].empty() ? 0 : (size_t)SMALL_MAXG1024 * 7 * (size_t)small_ns[2] * sizeof(double);
         if (h->small_cols_bytes < need1 + need2) {
             if (h->d_small_cols) (void)hipFree(h->d_small_cols);
             h->d_small_cols = nullptr;
@@ -1350,7 +1653,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             h->small_cols_bytes = need1 + need2;
         }
         P.small_cols = h->d_small_cols;
-        P.small_cols2 = (double *)((char *)h->d_small_cols + need1);
+        P.small_cols2 = need2 ? (double *)((char *)h->d_small_cols + need1) : nullptr;
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     TRACE("run: classified");
@@ -1407,6 +1710,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
     { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
+    // every persistent wave of the 512- / 1024-entry variants owns a slice of the streamed-column buffer: never more waves than slices
+    groups_small[0] = std::max(1, groups_small[0]);
+    groups_small[1] = std::min(std::max(1, groups_small[1]), SMALL_MAXG512);
+    groups_small[2] = std::min(std::max(1, groups_small[2]), SMALL_MAXG1024);
     auto launch_small = [&](int v, std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {
         if (list.empty()) return 0;
         soap_engine::Class &C = h->small[v];
@@ -1520,7 +1827,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (rc) return rc;
         // ... and the small-halo kernels with them: launched after the pipeline's iterations (whose host loop waits for every
         // iteration's verdicts) they and the clean-up launch behind them were a serial tail of ~2.4 ms on an eighth of the C3 box
-        static const bool small_late = getenv("SOAP_ENGINE_SMALL_LATE") && atoi(getenv("SOAP_ENGINE_SMALL_LATE")) != 0;
+        const bool small_late = getenv("SOAP_ENGINE_SMALL_LATE") && atoi(getenv("SOAP_ENGINE_SMALL_LATE")) != 0;
         if (!small_late && only_class < 0) {
             for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev_p[0], false);
             if (!rc) rc = launch_cleanup(false);
@@ -1613,7 +1920,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         };
         long long arena_used = 0;
         int props_iters = 0;   // giants' mode: iterations whose property passes were timed with their own events
-        std::vector<double> rbuild(n, 0.0);         // 0: the default first superset
+        std::vector<double> rbuild(h->h_first);     // 0: the default first superset; k_predict's guess otherwise
         std::vector<int> state(n), single[3];       // rows that end up on the single-kernel path
         std::vector<long long> off(n);
         std::vector<int> capv(n);
@@ -1668,7 +1975,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             int rc = 0;
             HIPCHECK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
-            if (iter == 0) HIPCHECK(hipMemsetAsync(d_rbuild, 0, n * 8, st));
+            if (iter == 0) HIPCHECK(hipMemcpyAsync(d_rbuild, rbuild.data(), n * 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_off, d_cap, (const double *)d_rbuild);
             // stage 1: small halos one thread group each; large halos (everything beyond the wavefront class) with
             // several workgroups per halo (k_g* kernels), on the stream of the 1024-thread class
@@ -1690,13 +1997,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     // beyond a few 1e5 entries the sample of the sample sort (2048 entries for at most GNBMAX buckets: one or two
                     // per bucket) is too thin -- a bucket outgrows its LDS block in one run in ten, which costs a millisecond of
                     // rank sort: uniform bins in radius instead (~128 entries per bin), as many bucket groups as the entries need
-                    static const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
+                    const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
                     const bool giant_sort = e > giant_sort_limit;
                     const int ng = giant_sort ? (int)(e / 1024 + 2) : (int)std::min<long long>(GNBMAX, e / 1024 + 2);   // groups hold more than half a 2048-entry block
                     // (bins of ~30 entries on average: a bin may hold up to half a block, and the bins at the core of a concentrated halo --
                     // or across a massive satellite -- hold tens of times the average once the build radius has been doubled twice; with
                     // ~120 per bin two halos of the uncapped C3 box fell back to ONE 1024-thread group each, 15 ms at the end of the pass)
-                    static const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
+                    const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
                     const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / giant_bin), 64) : 0;
                     bin_first.push_back(giant_sort ? (int)nbins_total : -1); nbinv.push_back(nbin);
                     if (giant_sort) nbins_total += 2ll * nbin + 1 + ng + 1;
@@ -1890,7 +2197,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         {
             // the thread-group classes first, largest groups first: a 1024-thread group needs an empty CU, and the waves of the
             // small-halo class (three per SIMD fill its registers) would never leave one
-            static const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
+            const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
             int rc = 0;
             const bool launch_small_now = !(small_early && pass == 0);   // (giants' mode: they started before the pipeline)
             if (small_first && launch_small_now) for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
@@ -2011,6 +2318,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     }
     h->ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     HIPCHECK(hipMemcpy(h->phase, h->d_phase, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipGetLastError();   // (the elapsed-time queries above report events a class without work never recorded: not an error of the run)
     return 0;
 }
 
@@ -2119,6 +2427,7 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_pipeline")) return (double)h->n_pipeline;
     if (!strcmp(name, "n_gbuild")) return (double)h->n_gbuild;
     if (!strcmp(name, "n_single")) return (double)h->n_single;
+    if (!strcmp(name, "n_predicted")) return (double)h->n_predicted;
     if (!strcmp(name, "n_passes")) return (double)h->n_passes;   // launches of the single-kernel path (more than one: slab overflows)
     if (!strcmp(name, "mesh")) return h->ms_mesh;
     if (!strcmp(name, "reorder")) return h->ms_reorder;

@@ -66,6 +66,7 @@ struct TypeDev {
     const unsigned *cell_offset;  // res^3 + 1 entries
     const Pay *pay;               // payload records in cell order
     double pos_min[3], pos_max[3], cell_size[3];
+    double mean_mass;             // of a thinned sample of the type's particles (the scheduling guess of k_predict)
 };
 
 struct SlabDev {
@@ -87,6 +88,7 @@ struct HaloDev {
     const int *todo;   // optional list of rows to process (retry pass), or null
     long long n_todo;
     const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
+    const double *first_radius;   // optional: radius the first sorted superset of a halo should reach (k_predict; 0 = the default)
 };
 
 // Per-halo record of the three-stage pipeline (build -> radius loop -> property passes): what the stages hand to
@@ -411,6 +413,7 @@ struct TypeG {   // same layout as TypeDev, pointers typed as global
     const GAS unsigned *cell_offset;
     const GAS Pay *pay;
     double pos_min[3], pos_max[3], cell_size[3];
+    double mean_mass;
 };
 static_assert(sizeof(TypeG) == sizeof(TypeDev), "TypeG mirrors TypeDev");
 

@@ -47,22 +47,37 @@ def _ptr(x, dtype, shape_tail=()):
     if _is_torch(x):
         import torch
 
-        tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dtype]
-        if x.dtype == torch.float32 and tdt == torch.float64:
-            # real snapshots hold Velocities / Masses in float32: widened here, as
-            # np.ascontiguousarray does for host arrays below.  The engine's arithmetic is fp64 throughout.
-            x = x.to(torch.float64)
+        tdt = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32}[dtype]
         if x.dtype != tdt:
             raise TypeError(f"expected torch dtype {tdt}, got {x.dtype}")
         if not x.is_contiguous():
             x = x.contiguous()
-        if x.is_cuda:
-            # the engine reads device inputs on its own streams, which are ordered after the legacy default stream
-            # only: whatever produced (or just widened / copied) this tensor on torch's current stream has to be done
-            torch.cuda.current_stream(x.device).synchronize()
         return C.c_void_p(x.data_ptr()), bool(x.is_cuda), x
     a = np.ascontiguousarray(x, dtype=dtype)
     return C.c_void_p(a.ctypes.data), False, a
+
+
+def _value_dtype(*arrays):
+    """Width the value arrays of one staging call go through the C ABI with (`value_bytes` of
+    soap_engine_stage_particles): float32 when every one of them is float32 -- what SWIFT snapshots hold for
+    Velocities and Masses; the engine widens on the device -- float64 otherwise (a float32 array among float64
+    ones is widened here)."""
+    def is32(x):
+        if _is_torch(x):
+            import torch
+
+            return x.dtype == torch.float32
+        return np.asarray(x).dtype == np.float32
+
+    return np.float32 if all(is32(x) for x in arrays) else np.float64
+
+
+def _as_value(x, dtype):
+    if _is_torch(x):
+        import torch
+
+        return x if dtype == np.float32 else x.to(torch.float64)
+    return x
 
 
 def mesh_resolution(nr_parts: int) -> int:
@@ -99,7 +114,6 @@ class Engine:
         self._check(self._lib.soap_engine_create(C.byref(cfg), C.byref(self._h)))
         self.n_halo = 0
         self.calcs = []
-        self._staged = {}
 
     def _check(self, rc):
         if rc != 0:
@@ -121,9 +135,10 @@ class Engine:
         n = int(pos.shape[0])
         if resolution is None:
             resolution = mesh_resolution(n)
+        vdt = _value_dtype(vel, mass)
         p_pos, dev, k1 = _ptr(pos, np.float64)
-        p_vel, dev2, k2 = _ptr(vel, np.float64)
-        p_m, dev3, k3 = _ptr(mass, np.float64)
+        p_vel, dev2, k2 = _ptr(_as_value(vel, vdt), vdt)
+        p_m, dev3, k3 = _ptr(_as_value(mass, vdt), vdt)
         if _is_torch(grnr):
             import torch
 
@@ -137,38 +152,49 @@ class Engine:
             raise ValueError("all particle arrays must live on the same side (host or device)")
         if tuple(pos.shape) != (n, 3) or tuple(vel.shape) != (n, 3):
             raise ValueError("Coordinates/Velocities must have shape (n, 3)")
+        if dev:
+            self._order_after_torch(pos)
         self._check(
             self._lib.soap_engine_stage_particles(
-                self._h, int(type_slot), n, p_pos, p_vel, p_m, p_g, gb, p_f, int(resolution),
-                1 if dev else 0,
+                self._h, int(type_slot), n, p_pos, p_vel, p_m, 4 if vdt == np.float32 else 8, p_g, gb, p_f,
+                int(resolution), 1 if dev else 0,
             )  # fmt: skip
         )
-        # device-resident velocities / masses / ids are read in place until the next staging of this slot
-        # (include/soap_engine.h, lifetime rule): hold on to them (they may be widened / contiguous copies)
-        self._staged[int(type_slot)] = (k2, k3, k4, k5) if dev else None
+        # (the call has consumed every array: include/soap_engine.h, lifetime rule)
+        del k1, k2, k3, k4, k5
+
+    def _order_after_torch(self, tensor):
+        """Device inputs are read on the engine's own stream: order it behind whatever torch has submitted to its
+        current stream (the producer of the tensors, their `.contiguous()` / widening copies) -- an event on the
+        device, not a host synchronisation per array."""
+        import torch
+
+        self._check(self._lib.soap_engine_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)))
 
     def clear_type(self, type_slot):
         """Mark a particle type as absent from the current chunk (type_slot 0..3, or "nu")."""
         if type_slot == "nu":
-            self._check(self._lib.soap_engine_stage_neutrinos(self._h, 0, None, None, None, 1, 0))
+            self._check(self._lib.soap_engine_stage_neutrinos(self._h, 0, None, None, None, 8, 1, 0))
         else:
-            self._check(self._lib.soap_engine_stage_particles(self._h, int(type_slot), 0, None, None, None, None, 4, None, 1, 0))
-        self._staged[type_slot] = None
+            self._check(self._lib.soap_engine_stage_particles(self._h, int(type_slot), 0, None, None, None, 8, None, 4, None, 1, 0))
 
     def stage_neutrinos(self, pos, mass, weight, resolution=None):
         """PartType6: Coordinates, Masses, Weights (SO mass profile only, SO_properties.py:380-395)."""
         n = int(pos.shape[0])
         if resolution is None:
             resolution = mesh_resolution(n)
+        vdt = _value_dtype(mass, weight)
         p_pos, dev, k1 = _ptr(pos, np.float64)
-        p_m, dev2, k2 = _ptr(mass, np.float64)
-        p_w, dev3, k3 = _ptr(weight, np.float64)
+        p_m, dev2, k2 = _ptr(_as_value(mass, vdt), vdt)
+        p_w, dev3, k3 = _ptr(_as_value(weight, vdt), vdt)
         if len({dev, dev2, dev3}) != 1:
             raise ValueError("all particle arrays must live on the same side (host or device)")
         if n and tuple(pos.shape) != (n, 3):
             raise ValueError("Coordinates must have shape (n, 3)")
-        self._check(self._lib.soap_engine_stage_neutrinos(self._h, n, p_pos, p_m, p_w, int(resolution), 1 if dev else 0))
-        self._staged["nu"] = (k2,) if dev else None
+        if dev:
+            self._order_after_torch(pos)
+        self._check(self._lib.soap_engine_stage_neutrinos(self._h, n, p_pos, p_m, p_w, 4 if vdt == np.float32 else 8, int(resolution), 1 if dev else 0))
+        del k1, k2, k3
 
     def stage_halos(self, cofp, search_radius, read_radius, index, is_central, nr_bound_part, resident_radius=None):
         """`resident_radius` (optional, per halo, >= read_radius): how far around the centre the staged particles

@@ -11,8 +11,17 @@ from .halo_properties import HaloProperty
 from .subhalo_properties import _property_filters
 
 
+_SO_DSETS = ("Coordinates", "FOFGroupIDs", "GroupNr_bound", "Masses", "Velocities")
+
+
 class SOProperties(HaloProperty):
     base_halo_type = "SOProperties"
+    # SO_properties.py:3520-3550 (the FOF ids feed MassFractionSatellites / External, PartType6 the neutrino masses)
+    _PARTICLE_DATASETS = {
+        "PartType0": _SO_DSETS, "PartType1": _SO_DSETS, "PartType4": _SO_DSETS,
+        "PartType5": ("Coordinates", "DynamicalMasses", "FOFGroupIDs", "GroupNr_bound", "Velocities"),
+        "PartType6": ("Coordinates", "Masses", "Weights"),
+    }  # fmt: skip
     property_names = [
         "r", "Mtot", "Ngas", "Ndm", "Nstar", "Nbh", "com", "vcom", "Vmax_soft", "R_vmax_soft",
         "Mfrac_satellites", "Mfrac_external", "Mgas", "Mdm", "Ldm", "Mstar", "Mbh_dynamical",

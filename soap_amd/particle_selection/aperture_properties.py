@@ -16,8 +16,17 @@ def _aperture_name(radius_kpc):
     return f"{radius_kpc:.0f}kpc"
 
 
+_AP_DSETS = ("Coordinates", "GroupNr_bound", "Masses", "Velocities")
+# aperture_properties.py:3995-4005, projected_aperture_properties.py:1770-1780
+APERTURE_PARTICLE_DATASETS = {
+    "PartType0": _AP_DSETS, "PartType1": _AP_DSETS, "PartType4": _AP_DSETS,
+    "PartType5": ("Coordinates", "DynamicalMasses", "GroupNr_bound", "Velocities"),
+}  # fmt: skip
+
+
 class ApertureProperties(HaloProperty):
     base_halo_type = "ApertureProperties"
+    _PARTICLE_DATASETS = APERTURE_PARTICLE_DATASETS
     property_names = [
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "veldisp_matrix_dm", "HalfMassRadiusDM", "Vmax_soft", "R_vmax_soft",

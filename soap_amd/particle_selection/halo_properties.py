@@ -57,6 +57,10 @@ class HaloProperty:
     halo_filter = "basic"
     kind = -1  # engine calculation kind
     property_names: List[str] = []  # internal keys, in output order
+    # datasets per particle type the calculation reads: what ChunkTask unions over halo_prop_list to decide what is
+    # read from the snapshot (SOAP/core/chunk_tasks.py:236-241) -- here exactly the datasets stage_chunk hands to
+    # soap_engine_stage_particles / _stage_neutrinos.  Subclasses name their table; every instance gets its own copy.
+    _PARTICLE_DATASETS: Dict[str, tuple] = {}
 
     def __init__(self, cellgrid):
         # fields copied from the cell grid (halo_properties.py:12-35)
@@ -73,6 +77,14 @@ class HaloProperty:
         self.physical_radius_mpc = 0.0
         self.category_filter = None
         self.property_filters: Dict[str, str] = {}
+        self.particle_properties = {ptype: list(dsets) for ptype, dsets in self._PARTICLE_DATASETS.items()}
+
+    @property
+    def property_list(self) -> Dict:
+        """key -> schema row of every property the class can emit (`property_list` of the reference's classes:
+        SO_properties.py:3233-3367, aperture_properties.py:3716-3873, ...); core/parameter_file.py:190 reads the
+        output names off its values to validate a parameter file."""
+        return {key: full_property_list[key] for key in self.property_names}
 
     # ---- engine description --------------------------------------------------------
     def calc_desc(self, halo_prop_list, position) -> CalcDesc:

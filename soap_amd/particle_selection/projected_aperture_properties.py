@@ -11,7 +11,7 @@ import numpy as np
 
 from .. import layout
 from ..property_table import full_property_list, stored_value
-from .aperture_properties import _aperture_name
+from .aperture_properties import APERTURE_PARTICLE_DATASETS, _aperture_name
 from .halo_properties import HaloProperty
 from .subhalo_properties import _property_filters
 
@@ -19,6 +19,7 @@ from .subhalo_properties import _property_filters
 class ProjectedApertureProperties(HaloProperty):
     base_halo_type = "ProjectedApertureProperties"
     kind = layout.CALC_PROJECTED
+    _PARTICLE_DATASETS = APERTURE_PARTICLE_DATASETS
     property_names = ["Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
                       "com", "vcom", "HalfMassRadiusDM", "proj_veldisp_dm",
                       "com_star", "proj_veldisp_gas", "proj_veldisp_star",

@@ -15,6 +15,13 @@ from .halo_properties import HaloProperty
 class SubhaloProperties(HaloProperty):
     base_halo_type = "SubhaloProperties"
     kind = layout.CALC_SUBHALO
+    # subhalo_properties.py:2557-2567
+    _PARTICLE_DATASETS = {
+        "PartType0": ("Coordinates", "Masses", "Velocities", "GroupNr_bound"),
+        "PartType1": ("Coordinates", "Masses", "Velocities", "GroupNr_bound"),
+        "PartType4": ("Coordinates", "Masses", "Velocities", "GroupNr_bound"),
+        "PartType5": ("Coordinates", "DynamicalMasses", "Velocities", "GroupNr_bound"),
+    }
     property_names = [
         "Mtot", "Mgas", "Mdm", "Mstar", "Mbh_dynamical", "Ngas", "Ndm", "Nstar", "Nbh",
         "com", "vcom", "Ldm", "Vmax_unsoft", "Vmax_soft", "R_vmax_unsoft", "spin_parameter",

@@ -279,3 +279,48 @@ def test_halo_result_wraps_into_the_tuples_result_set_append_takes():
     assert n[0].dtype == np.uint32 and n[0].units == unyt.Unit("dimensionless") and n[2] is True
     m = arrays["SO/200_crit/TotalMass"]
     assert m[0].units == unyt.Unit("snap_mass") and m[2] is True
+
+
+def test_facades_carry_what_chunk_task_and_the_parameter_file_read():
+    """`particle_properties` and `property_list` of every entry of halo_prop_list, driven the way the reference's callers
+    drive them: the property union of ChunkTask.__call__ (SOAP/core/chunk_tasks.py:220-241) and the parameter-file
+    validation (SOAP/core/parameter_file.py:176-195).  The union is exactly the set of datasets stage_chunk stages."""
+    from soap_amd.core.dataset_names import mass_dataset, ptypes_for_so_masses
+
+    sc = SnapshotScalars()
+    for dmo in (True, False):
+        cf = CategoryFilter(dmo=dmo)
+        props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 50.0)),
+                                         projected_vars=chp.projected_variations((30.0,)))
+        # chunk_tasks.py:220-241, statement for statement
+        properties = {}
+        need_so = False
+        for halo_prop in props:
+            if halo_prop.mean_density_multiple is not None or halo_prop.critical_density_multiple is not None:
+                need_so = True
+        assert need_so
+        for ptype in ptypes_for_so_masses:
+            properties[ptype] = set(["Coordinates", mass_dataset(ptype)])
+        for halo_prop in props:
+            for ptype in halo_prop.particle_properties:
+                if ptype not in properties:
+                    properties[ptype] = set()
+                properties[ptype] = properties[ptype].union(halo_prop.particle_properties[ptype])
+        staged = {"Coordinates", "Velocities", "Masses", "GroupNr_bound", "FOFGroupIDs"}
+        assert properties["PartType0"] == properties["PartType1"] == properties["PartType4"] == staged
+        assert properties["PartType5"] == (staged - {"Masses"}) | {"DynamicalMasses"}
+        assert properties["PartType6"] == {"Coordinates", "Masses", "Weights"}
+        # every instance owns its lists (the reference appends to them per instance)
+        props[1].particle_properties["PartType0"].append("Temperatures")
+        assert "Temperatures" not in props[2].particle_properties["PartType0"]
+        # parameter_file.py:176-195: names a parameter file may list for a halo type
+        for hp in props:
+            valid = [prop.name for prop in hp.property_list.values()]
+            assert len(valid) == len(hp.property_names) and all(isinstance(n, str) and n for n in valid)
+            assert set(hp.property_filters) <= set(valid)
+            for key in hp.enabled_properties():
+                assert hp.property_list[key].name in valid
+        assert "SORadius" in [p.name for p in props[1].property_list.values()]
+        assert "EncloseRadius" in [p.name for p in props[0].property_list.values()]
+        by_type = {hp.base_halo_type for hp in props}
+        assert by_type == {"SubhaloProperties", "SOProperties", "ApertureProperties", "ProjectedApertureProperties"}

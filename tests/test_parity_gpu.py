@@ -356,10 +356,13 @@ def test_per_halo_calculate_protocol(built_library):
 
 
 def test_device_resident_float32_inputs(built_library):
-    """Real snapshots hold Velocities/Masses in float32 and the chunk may already live in HBM: device
-    tensors (float32 values widened on the device) must give exactly the table of the same values passed
-    as host float64 arrays."""
+    """Real snapshots hold Velocities/Masses in float32 and the chunk may already live in HBM: float32 POINTERS go
+    through the C ABI (`value_bytes` = 4 of soap_engine_stage_particles, widened on the device by the placement
+    pass), as device tensors and as host arrays, and give exactly the table of the same values passed as host
+    float64 arrays.  A float32 mass array beside float64 velocities is widened on the way in (one width per call)."""
     import torch
+
+    from soap_amd import engine as engine_mod
 
     sc, data, halos = make_chunk(50000, 30, seed=17)
     data_np, halos_np = to_numpy(data, halos)
@@ -370,7 +373,7 @@ def test_device_resident_float32_inputs(built_library):
     props = chp.build_halo_prop_list(sc, cf, {"200_crit": {"value": 200.0, "type": "crit"}},
                                      chp.aperture_variations((50.0,)))  # fmt: skip
     e1, ha1, r1, o1 = _run_engine(sc, data_np, halos_np, props)
-    data_dev = {}
+    data_dev, data_h32, data_mixed = {}, {}, {}
     for pt, d in data_np.items():
         data_dev[pt] = {
             "Coordinates": torch.from_numpy(d["Coordinates"]).cuda(),
@@ -379,12 +382,30 @@ def test_device_resident_float32_inputs(built_library):
             "GroupNr_bound": torch.from_numpy(d["GroupNr_bound"]).cuda(),
             "FOFGroupIDs": torch.from_numpy(d["FOFGroupIDs"]).cuda(),
         }
-    e2, ha2, r2, o2 = _run_engine(sc, data_dev, halos_np, props)
-    del data_dev   # the engine's Python side keeps what the kernels read in place
-    assert np.array_equal(o1[4]["status"], o2[4]["status"])
-    assert np.array_equal(o1[4]["table"], o2[4]["table"])
-    e1.close()
-    e2.close()
+        data_h32[pt] = dict(d, Velocities=d["Velocities"].astype(np.float32), Masses=d["Masses"].astype(np.float32))
+        data_mixed[pt] = dict(d, Masses=d["Masses"].astype(np.float32))
+    # what crosses the boundary: 4-byte values when both arrays are float32, 8-byte otherwise
+    widths = []
+    real = engine_mod.Engine.stage_particles
+
+    def spy(self, type_slot, pos, vel, mass, grnr, fof, resolution=None):
+        widths.append(np.dtype(engine_mod._value_dtype(vel, mass)).itemsize)
+        return real(self, type_slot, pos, vel, mass, grnr, fof, resolution)
+
+    engine_mod.Engine.stage_particles = spy
+    try:
+        e2, ha2, r2, o2 = _run_engine(sc, data_dev, halos_np, props)
+        del data_dev   # (the staging call has consumed the arrays: include/soap_engine.h, lifetime rule)
+        e3, ha3, r3, o3 = _run_engine(sc, data_h32, halos_np, props)
+        e4, ha4, r4, o4 = _run_engine(sc, data_mixed, halos_np, props)
+    finally:
+        engine_mod.Engine.stage_particles = real
+    assert widths == [4, 4, 8]
+    for o in (o2, o3, o4):
+        assert np.array_equal(o1[4]["status"], o[4]["status"])
+        assert np.array_equal(o1[4]["table"], o[4]["table"])
+    for e in (e1, e2, e3, e4):
+        e.close()
 
 
 def test_chunk_harness_columns_match_per_halo_results(built_library, tmp_path):

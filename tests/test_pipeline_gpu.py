@@ -215,3 +215,31 @@ def test_oversized_sort_buckets_are_ranked(built_library, monkeypatch):
     assert np1 == 0 and ns2 == 0 and np2 == len(halos_np["index"]) and n_gbuild > 20, (np1, np2, ns2, n_gbuild)
     assert np.array_equal(raw1["status"], raw2["status"]) and np.array_equal(raw1["stats"][:, :3], raw2["stats"][:, :3])
     assert np.array_equal(t1, t2)
+
+
+def test_more_than_32_so_thresholds_through_the_tile_parallel_build(built_library, monkeypatch):
+    """MAXCALC is 64: a run may carry more than 32 SO density definitions, and the tile kernel that tabulates the first
+    entry below each threshold (k_gpost) keeps one bit per threshold and thread -- 64 of them.  With 40 thresholds the
+    large halos built by several workgroups must give the table of the single-kernel path."""
+    monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", "600")
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
+    sc, data, halos = make_chunk(250000, 120, seed=48, read_radius_factor=8.0)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    so_vars = {f"{v:.0f}_crit": {"value": float(v), "type": "crit"} for v in np.linspace(60.0, 3180.0, 40).round()}
+    props = chp.build_halo_prop_list(sc, cf, so_vars, {}, parameters=_NoInertia())
+    assert sum(p.kind == 1 for p in props) == 40
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha1, _, raw1, t1, _ = _run(engine, props, sc, halos_np, pipeline=False)
+    ha2, _, raw2, t2, (np2, _) = _run(engine, props, sc, halos_np, pipeline=2)
+    assert np2 > 0.8 * len(halos_np["index"]) and engine.kernel_ms("n_gbuild") > 0.3 * len(halos_np["index"])
+    assert np.array_equal(raw1["status"], raw2["status"]) and np.array_equal(raw1["stats"][:, :3], raw2["stats"][:, :3])
+    assert np.array_equal(t1, t2)
+    # the SO radii of the last thresholds (bits 32 .. 39 of the mask) are there and differ from those 32 places earlier
+    cols = [engine.desc_columns(p.calc_desc(props, i)) for i, p in enumerate(props)]
+    off = np.concatenate([[0], np.cumsum(cols)])
+    r_hi, r_lo = t2[:, off[1 + 39]], t2[:, off[1 + 7]]
+    ok = raw2["status"] == 0
+    assert np.all(r_hi[ok] > 0.0) and np.all(r_hi[ok] < r_lo[ok])
+    engine.close()

@@ -200,3 +200,28 @@ def test_small_class_inertia_tensors_with_restarts_inside_the_resident_radius(bu
     _same_selections(ha4, raw4, ha0, raw0)
     scale = np.maximum(np.maximum(np.abs(t4), np.abs(t0)).max(axis=0, keepdims=True), 1e-300)
     assert np.all(np.abs(t4 - t0) <= 1e-9 * np.abs(t0) + 1e-12 * scale)
+
+
+def test_escalation_without_the_device_hand_over_list(built_library, monkeypatch):
+    """SOAP_ENGINE_SMALL_HANDOVER=0: halos that outgrow the small-halo class' slab are not handed on inside the pass; they
+    come back with the overflow status and the host escalates them to the wavefront class in a pass of its own (the
+    `next[0]` path of soap_engine_run).  The switch is read on every run, so one process can compare both ways: same
+    selections, same table."""
+    sc, data, halos = make_chunk(250000, 300, seed=73, read_radius_factor=8.0)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)), parameters=_NoInertia())
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    ha_a, _, raw_a, t_a, (n_a, e_a) = _run(engine, props, sc, halos_np, 2, monkeypatch)
+    passes_a = engine.kernel_ms("n_passes")
+    monkeypatch.setenv("SOAP_ENGINE_SMALL_HANDOVER", "0")
+    ha_b, _, raw_b, t_b, (n_b, e_b) = _run(engine, props, sc, halos_np, 2, monkeypatch)
+    passes_b = engine.kernel_ms("n_passes")
+    monkeypatch.delenv("SOAP_ENGINE_SMALL_HANDOVER")
+    assert e_a > 0 and e_b == e_a and n_b == n_a, (n_a, e_a, n_b, e_b)
+    assert passes_a == 1 and passes_b == 2, (passes_a, passes_b)   # the escalated halos needed a second launch of the wavefront class
+    _same_selections(ha_a, raw_a, ha_b, raw_b)
+    assert np.array_equal(t_a, t_b)
+    assert np.all(raw_b["status"] >= 0)
+    engine.close()
