@@ -1614,8 +1614,16 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             const bool use1024 = !want_inertia && getenv("SOAP_ENGINE_SMALL1024") && atoi(getenv("SOAP_ENGINE_SMALL1024")) != 0;
             std::vector<int> rest;
             rest.reserve(todo[0].size());
+            // A halo that is certain to outgrow the largest LDS slab in use is done by the wavefront class after the small-halo
+            // kernels -- one wave per halo, 4e-7 s per candidate: the longest of them are the chains that clean-up launch ends with,
+            // alone on the GPU.  Above nb_overflow candidates such a halo goes to the 256-thread class from the start instead.
+            long long nb_overflow = 1ll << 62;
+            { const char *e = getenv("SOAP_ENGINE_NB_OVERFLOW"); if (e) nb_overflow = atoll(e); }
+            const double small_fit = (double)(use1024 ? small_ns[2] : (use512 ? small_ns[1] : small_ns[0]));
+            std::vector<int> to_medium;
             for (int i : todo[0]) {
                 const double pred = (double)h->h_nrbound[i] * small_factor + 4.0;
+                if (small_mode == 4 && est[i] > nb_overflow && pred > small_fit) { to_medium.push_back(i); continue; }
                 int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : (pred <= (double)small_ns[2] && use1024 ? 2 : -1));
                 if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry / the 1024-entry variant)
                 if (small_mode == 3) v = 1;
@@ -1624,6 +1632,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
             todo[0].swap(rest);
+            if (!to_medium.empty()) {
+                // (todo[1] is in descending order of the estimates, all above those of the wavefront class: these follow)
+                todo[1].insert(todo[1].end(), to_medium.begin(), to_medium.end());
+            }
         }
     }
     // (diagnostic switches are read on every run, like SOAP_ENGINE_SMALL above: a sweep that toggles them inside one process measures what it says)

@@ -27,7 +27,8 @@ def _line(cmd, env):
 
 def test_two_rank_rehearsal_prints_the_line_of_the_whole_job(built_library):
     env = dict(os.environ, BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", BENCH_RANK_CUT="work")
-    common = ["--steps", "1", "--warmup", "0", "--passes-per-step", "2", "--workload", "c2", "--no-cpu-baseline"]
+    # the configuration of the driver's scaling run: the seed-1234 C3 box (1e8 particles, 1e5 halos), both ranks on this one GPU
+    common = ["--steps", "1", "--warmup", "0", "--passes-per-step", "1", "--workload", "c3", "--no-cpu-baseline"]
     port = 29700 + (os.getpid() % 2000)
     two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                  "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)  # fmt: skip
