@@ -372,6 +372,14 @@ void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev are
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
                         const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
 void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart);
+void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int teams, int K, int split,
+                      const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
+                      const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan);
+}
+
+// team run: one word per large halo for the host (the state its team left it in)
+__global__ void k_team_states(const HaloHdr *hdr, const int *rows, long long n, int *state) {
+    for (long long i = blockIdx.x * (long long)BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) state[i] = hdr[rows[i]].pipe_state;
 }
 
 // pipeline bookkeeping kernels: the records start out empty except for the arena slice; the host only ever reads
@@ -827,6 +835,12 @@ struct soap_engine {
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
+    // team run (k_team): its own stream (highest priority: launched first, resident from the start), control block, clocks
+    hipStream_t team_stream = nullptr;
+    hipEvent_t team_start = nullptr, team_done = nullptr;
+    TeamCtl *d_teamctl = nullptr;
+    double ms_team = 0.0;
+    long long n_team = 0, n_team_failed = 0;
 };
 
 static void free_slab(soap_engine::Class &c) {
@@ -969,6 +983,11 @@ static int32_t create_resources(soap_engine *h) {
             HIPCHECK(hipMalloc((void **)&h->small[v].d_queue, sizeof(unsigned)));
         }
     }
+    if (h->own_streams) HIPCHECK(hipStreamCreateWithPriority(&h->team_stream, hipStreamNonBlocking, prio_greatest));
+    else HIPCHECK(hipStreamCreate(&h->team_stream));
+    HIPCHECK(hipEventCreate(&h->team_start));
+    HIPCHECK(hipEventCreate(&h->team_done));
+    HIPCHECK(hipMalloc((void **)&h->d_teamctl, sizeof(TeamCtl)));
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_params_pipe, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
@@ -1021,6 +1040,10 @@ int32_t soap_engine_destroy(soap_engine *h) {
         if (h->small[v].start) (void)hipEventDestroy(h->small[v].start);
         if (h->small[v].stream) (void)hipStreamDestroy(h->small[v].stream);
     }
+    if (h->team_start) (void)hipEventDestroy(h->team_start);
+    if (h->team_done) (void)hipEventDestroy(h->team_done);
+    if (h->team_stream) (void)hipStreamDestroy(h->team_stream);
+    if (h->d_teamctl) (void)hipFree(h->d_teamctl);
     probe("class resources");
     if (h->d_first) (void)hipFree(h->d_first);
     if (h->d_small_cols) (void)hipFree(h->d_small_cols);
@@ -1791,6 +1814,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
     std::vector<int> early[3];
     const bool hybrid = pipeline && pmode == 1;
+    // SOAP_ENGINE_PIPELINE=4: the large halos go to TEAMS of workgroups inside one persistent launch (k_team) instead of the
+    // multi-launch pipeline; everything else stays on the single-kernel path
+    const bool teams = pipeline && pmode == 4;
+    if (teams) pipeline = false;
     bool giants = pipeline && pmode == 3;
     if (giants) {
         // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
@@ -2178,6 +2205,134 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (int k = 0; k < 3; k++) { single[k].insert(single[k].end(), todo[k].begin(), todo[k].end()); todo[k].swap(single[k]); }
         pipe_scratch.ok = true;   // (released by the guard)
     }
+    // ---- teams: the halos beyond nb_team candidates, heaviest first, T teams of K workgroups
+    std::vector<int> team_rows;
+    long long *d_toff = nullptr; int *d_tcap = nullptr, *d_tstate = nullptr; double *d_trb = nullptr;
+    struct TeamScratch {
+        soap_engine *h; size_t n, L; long long *&off; int *&cap, *&state; double *&rb;
+        ~TeamScratch() { h->pool.release(off, n * 8); h->pool.release(cap, n * 4); h->pool.release(state, L * 4); h->pool.release(rb, n * 8); }
+    } team_scratch{h, (size_t)h->n_halo, 0, d_toff, d_tcap, d_tstate, d_trb};
+    h->n_team = h->n_team_failed = 0;
+    h->ms_team = 0.0;
+    if (teams) {
+        long long nb_team = 49152;
+        { const char *e = getenv("SOAP_ENGINE_NB_TEAM"); if (e) nb_team = atoll(e); }
+        for (int k = 1; k < 3; k++) {
+            std::vector<int> keep;
+            for (int i : todo[k]) (est[i] > nb_team ? team_rows : keep).push_back(i);
+            todo[k].swap(keep);
+        }
+        std::sort(team_rows.begin(), team_rows.end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
+    }
+    if (!team_rows.empty()) {
+        const size_t n = (size_t)h->n_halo, L = team_rows.size();
+        team_scratch.L = L;
+        int K = 4, T = 32;
+        { const char *e = getenv("SOAP_ENGINE_TEAM_K"); if (e) K = std::max(1, std::min(16, atoi(e))); }
+        { const char *e = getenv("SOAP_ENGINE_TEAMS"); if (e) T = atoi(e); }
+        T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(T, TEAM_MAX), (long long)L));
+        if (h->hdr_bytes < n * sizeof(HaloHdr)) {
+            if (h->d_hdr) (void)hipFree(h->d_hdr);
+            h->d_hdr = nullptr;
+            HIPCHECK(hipMalloc((void **)&h->d_hdr, n * sizeof(HaloHdr)));
+            h->hdr_bytes = n * sizeof(HaloHdr);
+        }
+        std::vector<long long> off(n, 0);
+        std::vector<int> capv(n, 0);
+        std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, tile_li, gblock_li, sel_li, bin_first, nbinv;
+        long long total = 0, nbins_total = 0;
+        const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
+        const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
+        for (size_t li = 0; li < L; li++) {
+            const int i = team_rows[li];
+            // room for the sphere the guess reaches and for one rebuild further out (the team checks before it builds again)
+            long long c = next_pow2(std::max<long long>(est[i] + est[i] / 2, 4096));
+            c = std::min<long long>(c, cap_max);
+            off[i] = total; capv[i] = (int)c; total += c;
+            const bool giant_sort = est[i] > giant_sort_limit;
+            const int nt = (int)((c + GTILE - 1) / GTILE);
+            const int ng = giant_sort ? (int)(c / 1024 + 2) : (int)std::min<long long>(GNBMAX, c / 1024 + 2);
+            const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(c / giant_bin), 64) : 0;
+            const int ns = (int)((c + 16383) / 16384);
+            rows.push_back(i);
+            bin_first.push_back(giant_sort ? (int)nbins_total : -1); nbinv.push_back(nbin);
+            if (giant_sort) nbins_total += 2ll * nbin + 1 + ng + 1;
+            first_tile.push_back((int)tile_li.size()); ntile.push_back(nt);
+            first_gblock.push_back((int)gblock_li.size()); ngblock.push_back(ng);
+            first_sel.push_back((int)sel_li.size()); nsel.push_back(ns);
+            sel_li.insert(sel_li.end(), (size_t)ns, (int)li);
+            tile_li.insert(tile_li.end(), (size_t)nt, (int)li);
+            gblock_li.insert(gblock_li.end(), (size_t)ng, (int)li);
+        }
+        { int rc0 = alloc_arena(h, total); if (rc0) return rc0; }
+        if (h->gb_count < L) {
+            if (h->d_gb) (void)hipFree(h->d_gb);
+            h->d_gb = nullptr;
+            h->gb_count = L + L / 4 + 16;
+            HIPCHECK(hipMalloc((void **)&h->d_gb, h->gb_count * sizeof(GBuild)));
+        }
+        if (nbins_total > 0x7fffffffll) return fail(-102, "teams: too many radial bins for one run");
+        if (h->gbins_count < (size_t)nbins_total) {
+            if (h->d_gbins) (void)hipFree(h->d_gbins);
+            h->d_gbins = nullptr;
+            h->gbins_count = (size_t)nbins_total + (size_t)nbins_total / 4 + 64;
+            HIPCHECK(hipMalloc((void **)&h->d_gbins, h->gbins_count * sizeof(int)));
+        }
+        const std::vector<int> *parts[12] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li, &bin_first, &nbinv};
+        size_t nints = 0;
+        for (int q = 0; q < 12; q++) nints += parts[q]->size();
+        if (h->gints_count < nints) {
+            if (h->d_gints) (void)hipFree(h->d_gints);
+            h->d_gints = nullptr;
+            h->gints_count = nints + nints / 4 + 64;
+            HIPCHECK(hipMalloc((void **)&h->d_gints, h->gints_count * sizeof(int)));
+        }
+        const size_t ntiles_total = tile_li.size();
+        const size_t need_bp = ntiles_total * 2 * (NACC + BSCAN_W);
+        if (h->bpart_count[0] < need_bp) {
+            if (h->d_bpart[0]) (void)hipFree(h->d_bpart[0]);
+            h->d_bpart[0] = nullptr;
+            h->bpart_count[0] = need_bp + need_bp / 4;
+            HIPCHECK(hipMalloc((void **)&h->d_bpart[0], h->bpart_count[0] * sizeof(double)));
+        }
+        HIPCHECK(h->pool.alloc((void **)&d_toff, n * 8));
+        HIPCHECK(h->pool.alloc((void **)&d_tcap, n * 4));
+        HIPCHECK(h->pool.alloc((void **)&d_tstate, L * 4));
+        HIPCHECK(h->pool.alloc((void **)&d_trb, n * 8));
+        hipStream_t ts = h->team_stream;
+        HIPCHECK(hipStreamWaitEvent(ts, h->ev_p[0], 0));
+        int *d = h->d_gints;
+        int *dptr[12];
+        for (int q = 0; q < 12; q++) {
+            dptr[q] = d;
+            HIPCHECK(hipMemcpyAsync(d, parts[q]->data(), parts[q]->size() * sizeof(int), hipMemcpyHostToDevice, ts));
+            d += parts[q]->size();
+        }
+        HIPCHECK(hipMemcpyAsync(d_toff, off.data(), n * 8, hipMemcpyHostToDevice, ts));
+        HIPCHECK(hipMemcpyAsync(d_tcap, capv.data(), n * 4, hipMemcpyHostToDevice, ts));
+        HIPCHECK(hipMemcpyAsync(d_trb, h->h_first.data(), n * 8, hipMemcpyHostToDevice, ts));
+        RunParams PT = P;
+        PT.hdr = h->d_hdr; PT.gb = h->d_gb; PT.tile_li = dptr[5]; PT.gblock_li = dptr[6]; PT.sel_li = dptr[9]; PT.gbins = h->d_gbins;
+        PT.rebuild_factor = 1.6;
+        { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) PT.rebuild_factor = atof(e); }
+        PT.g_coarse = getenv("SOAP_ENGINE_G_COARSE") != nullptr && atoi(getenv("SOAP_ENGINE_G_COARSE")) != 0;
+        HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &PT, sizeof(RunParams), hipMemcpyHostToDevice, ts));
+        HIPCHECK(hipMemsetAsync(h->d_teamctl, 0, sizeof(TeamCtl), ts));
+        hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, ts, h->d_hdr, (long long)n, d_toff, d_tcap, (const double *)d_trb);
+        bool any_projected = false;
+        for (int c = 0; c < n_calcs; c++) any_projected = any_projected || calcs[c].kind == SOAP_CALC_PROJECTED;
+        const int split = (!P.hydro && !any_projected && !(getenv("SOAP_ENGINE_SPLIT_PROPS") && atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) == 0)) ? 1 : 0;
+        const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
+        double *bpart = use_bpartials ? h->d_bpart[0] : nullptr;
+        HIPCHECK(hipEventRecord(h->team_start, ts));
+        soap_launch_team(ts, h->d_params_pipe, h->arena, h->d_teamctl, (long long)L, T, K, split, dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8],
+                         dptr[10], dptr[11], bpart, bpart ? bpart + ntiles_total * 2 * NACC : nullptr);
+        hipLaunchKernelGGL(k_team_states, dim3((unsigned)std::min<size_t>((L + BLK - 1) / BLK, 256)), dim3(BLK), 0, ts, (const HaloHdr *)h->d_hdr, (const int *)dptr[0], (long long)L, d_tstate);
+        HIPCHECK(hipEventRecord(h->team_done, ts));
+        HIPCHECK(hipGetLastError());
+        h->n_team = (long long)L;
+        if (trace) { fprintf(stderr, "[soap_engine] teams: %zu halos above %lld candidates (largest %lld), %d teams of %d groups, arena %lld entries, %zu tiles\n", L, (long long)est[team_rows.back()], (long long)est[team_rows[0]], T, K, total, ntiles_total); fflush(stderr); }
+    }
     TRACE("run: single-kernel part");
     h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size() + todo_small[2].size());
     std::vector<int> status(h->n_halo);
@@ -2232,6 +2387,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipStreamWaitEvent(st, h->cls[k].done, 0));
             }
         }
+        if (pass == 0 && !team_rows.empty()) { any = true; HIPCHECK(hipStreamWaitEvent(st, h->team_done, 0)); }
         if (!any) break;
         h->n_passes++;
         HIPCHECK(hipEventRecord(h->ev1, st));
@@ -2249,6 +2405,35 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // escalate halos whose search sphere did not fit their class' slab
         std::vector<int> next[3];
         bool grow_top = false;
+        if (pass == 0 && !team_rows.empty()) {
+            // what the teams left undone (radius ties, bound counts that disagree with the catalogue, a sphere beyond the arena
+            // slice) goes to the single-kernel path in the next pass
+            HIPCHECK(hipStreamSynchronize(h->team_stream));
+            std::vector<int> tstate(team_rows.size());
+            unsigned ctl_head[2] = {0u, 0u};
+            HIPCHECK(hipMemcpy(tstate.data(), d_tstate, team_rows.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(ctl_head, h->d_teamctl, sizeof(ctl_head), hipMemcpyDeviceToHost));
+            if (ctl_head[1] != 0u) return fail(-103, "team kernel: a team barrier timed out");
+            if (trace) {
+                TeamCtl hc;
+                HIPCHECK(hipMemcpy(&hc, h->d_teamctl, sizeof(TeamCtl), hipMemcpyDeviceToHost));
+                static const char *nm[15] = {"queue", "select", "split", "hist", "scan", "scatter", "sort", "gather", "cumsum", "post", "final+stage_a", "rebuild/idle", "tile sums", "tile scans", "props"};
+                unsigned long long tot = 0; for (int k = 0; k < 15; k++) tot += hc.phase[k];
+                fprintf(stderr, "[soap_engine] team phases (member 0, share of its clocks):");
+                for (int k = 0; k < 15; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.phase[k] / (double)std::max<unsigned long long>(tot, 1));
+                fprintf(stderr, "\n"); fflush(stderr);
+            }
+            float m2 = 0;
+            (void)hipEventElapsedTime(&m2, h->team_start, h->team_done);
+            h->ms_team = m2;
+            for (size_t li = 0; li < team_rows.size(); li++)
+                if (tstate[li] != PIPE_DONE) {
+                    const int i = team_rows[li];
+                    next[est[i] <= nb_medium ? 1 : 2].push_back(i);
+                    h->n_team_failed++;
+                    if (trace) { fprintf(stderr, "[soap_engine] teams: row %d (estimate %lld) left in state %d: single-kernel path\n", i, (long long)est[i], tstate[li]); fflush(stderr); }
+                }
+        }
         if (pass == 0 && P.small_esc != nullptr && (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())) {
             int nesc = 0;
             HIPCHECK(hipMemcpy(&nesc, h->d_small_esc, sizeof(int), hipMemcpyDeviceToHost));
@@ -2440,6 +2625,9 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_gbuild")) return (double)h->n_gbuild;
     if (!strcmp(name, "n_single")) return (double)h->n_single;
     if (!strcmp(name, "n_predicted")) return (double)h->n_predicted;
+    if (!strcmp(name, "n_team")) return (double)h->n_team;
+    if (!strcmp(name, "n_team_failed")) return (double)h->n_team_failed;
+    if (!strcmp(name, "halo_team")) return h->ms_team;
     if (!strcmp(name, "n_passes")) return (double)h->n_passes;   // launches of the single-kernel path (more than one: slab overflows)
     if (!strcmp(name, "mesh")) return h->ms_mesh;
     if (!strcmp(name, "reorder")) return h->ms_reorder;

@@ -165,6 +165,17 @@ struct GBuild {
     int gstart[GNBMAX + 1];
 };
 
+// Control block of the team kernel (k_team, halo_kernel.inc): the queue of large halos and one slot per team -- the team's
+// arrival counter (monotonic over the launch) and the list entry it works on -- each on a 128-byte line of its own.
+#define TEAM_MAX 64
+struct TeamCtl {
+    unsigned next;          // next entry of the list of large halos
+    unsigned abort;         // a team barrier timed out (a bug, or a team member that never became resident): every group leaves
+    unsigned pad0[30];
+    unsigned long long phase[32];   // shader clocks of member 0 per phase, summed over the halos (diagnostic)
+    struct Slot { unsigned arrive, task, pad[30]; } team[TEAM_MAX];
+};
+
 struct RunParams {
     TypeDev t[NT_ALL];
     SlabDev slab;

@@ -96,6 +96,14 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
     hipLaunchKernelGGL(k_gpost, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
+// records of the large halos of a team run (k_ginit), then the team kernel: T teams of K workgroups, one persistent launch
+extern "C" void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int teams, int K, int split,
+                                 const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
+                                 const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan) {
+    if (nlarge <= 0 || teams <= 0) return;
+    hipLaunchKernelGGL(k_ginit, dim3((unsigned)((nlarge + 63) / 64)), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, bin_first, nbin);
+    hipLaunchKernelGGL(k_team, dim3((unsigned)(teams * K)), dim3(GRP), 0, stream, params, arena, ctl, nlarge, K, split, bpart, bscan);
+}
 // tile sums for the property stage of the large halos whose radius loop has finished (k_bpartials)
 extern "C" void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart) {
     if (ntiles <= 0) return;

@@ -243,3 +243,44 @@ def test_more_than_32_so_thresholds_through_the_tile_parallel_build(built_librar
     ok = raw2["status"] == 0
     assert np.all(r_hi[ok] > 0.0) and np.all(r_hi[ok] < r_lo[ok])
     engine.close()
+
+
+@pytest.mark.parametrize("hydro,seed,read_factor,nb_team,team_k,giant_sort",
+                         [(False, 51, 8.0, 600, 4, None), (True, 52, 1.5, 2000, 3, None), (False, 53, 1.5, 600, 2, 3000), (False, 54, 8.0, 600, 1, None)])
+def test_teams_equal_the_single_kernel_path(built_library, monkeypatch, hydro, seed, read_factor, nb_team, team_k, giant_sort):
+    """SOAP_ENGINE_PIPELINE=4: the halos beyond nb_team candidates are done by TEAMS of workgroups inside one persistent
+    launch (k_team: the phases of the tile-parallel build, the one-lane radius loop, rebuilds further out, tile sums, the
+    property passes, with a team barrier between them) beside the single-kernel path of the others.  Same sorted slabs, same
+    property passes: the table of the single-kernel path bit for bit (tile sums off), to rounding with them."""
+    monkeypatch.setenv("SOAP_ENGINE_NB_TEAM", str(nb_team))
+    monkeypatch.setenv("SOAP_ENGINE_TEAM_K", str(team_k))
+    monkeypatch.setenv("SOAP_ENGINE_TEAMS", "6")
+    monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", str(nb_team // 2))   # (the 256-thread class on the single-kernel side for the same halos)
+    if giant_sort is not None:
+        monkeypatch.setenv("SOAP_ENGINE_GIANT_SORT", str(giant_sort))
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "0")
+    sc, data, halos = make_chunk(250000, 180, seed=seed, hydro=hydro, satellite_fraction=0.1, read_radius_factor=read_factor)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=not hydro)
+    ap_vars = chp.aperture_variations((30.0, 50.0, 100.0))
+    pj_vars = chp.projected_variations((30.0, 100.0)) if hydro else {}
+    props = chp.build_halo_prop_list(sc, cf, None, ap_vars, projected_vars=pj_vars, parameters=_NoInertia())
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    resident = 4.0 * halos_np["read_radius"] if read_factor < 2.0 else None   # (restarts and rebuilds inside the engine)
+    ha1, res1, raw1, t1, _ = _run(engine, props, sc, halos_np, pipeline=False, resident=resident)
+    ha2, res2, raw2, t2, _ = _run(engine, props, sc, halos_np, pipeline=4, resident=resident)
+    n_team, n_failed = engine.kernel_ms("n_team"), engine.kernel_ms("n_team_failed")
+    assert n_team > 0.2 * len(halos_np["index"]) and n_failed <= 0.1 * n_team, (n_team, n_failed)
+    assert np.array_equal(raw1["status"], raw2["status"]) and np.array_equal(ha1["done"], ha2["done"])
+    assert np.array_equal(ha1["read_radius"], ha2["read_radius"]) and np.array_equal(ha1["search_radius"], ha2["search_radius"])
+    assert np.array_equal(raw1["stats"][:, [0, 1, 2, 4, 5]], raw2["stats"][:, [0, 1, 2, 4, 5]])
+    bad = np.argwhere(t1 != t2)
+    assert bad.size == 0, (len(bad), [(int(r), engine_columns(engine, props, int(c))) for r, c in bad[:6]])
+    # ... with the tile sums and tile scans of the property stage (another order of the same additions)
+    monkeypatch.setenv("SOAP_ENGINE_BPARTIALS", "1")
+    ha3, _, raw3, t3, _ = _run(engine, props, sc, halos_np, pipeline=4, resident=resident)
+    assert np.array_equal(raw1["status"], raw3["status"]) and np.array_equal(raw1["stats"][:, [0, 1, 2, 4, 5]], raw3["stats"][:, [0, 1, 2, 4, 5]])
+    scale = np.maximum(np.abs(t1).max(axis=0, keepdims=True), 1e-300)
+    assert np.all(np.abs(t3 - t1) <= 1e-11 * np.abs(t1) + 1e-13 * scale)
+    engine.close()
