@@ -297,7 +297,7 @@ def main():
 
     g.build()
     from soap_amd import layout
-    from soap_amd.catalogue import gather_catalogue_packed
+    from soap_amd.catalogue import gather_catalogue_packed, spatial_sort_order_device
     from soap_amd.core.result_set import PackedLayout
     from soap_amd.core import chunk_tasks, halo_tasks
     from soap_amd.synthetic import make_chunk
@@ -366,6 +366,10 @@ def main():
                         status = np.full(H, -99, dtype=np.int32)
                     stats[rows[okm]] = raw["stats"][okm]
                     status[rows] = raw["status"]
+                direct = it == 0 and rows.size == H and okm.all()   # every halo finished in the first call: the stored catalogue is packed straight from the engine's table
+                if direct:
+                    state["npass"] += 1
+                    break
                 if table is None:
                     state["ncols"] = engine.row_columns
                     table = state["table"] = torch.zeros((H, state["ncols"]), dtype=torch.float64, device=dev)
@@ -390,8 +394,14 @@ def main():
             state["raw"] = dict(stats=stats, status=status, iterations=it + 1,
                                 radius_updates=int(np.sum(ha["read_radius"] != halos_np["read_radius"])))
             # final catalogue: concatenation over the ranks in (cell, catalogue index) order
-            narrow, wide = packed.pack(table)
-            state["catalogue"] = gather_catalogue_packed(narrow, wide, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
+            if direct and world == 1:
+                # one rank: the engine writes the stored columns in final-catalogue order (soap_engine_pack_catalogue)
+                o = spatial_sort_order_device(d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
+                narrow, wide = packed.pack_engine(engine, dev, order=o)
+                state["catalogue"] = (narrow, wide, d_cofp[o], d_index[o])
+            else:
+                narrow, wide = packed.pack_engine(engine, dev) if direct else packed.pack(table)
+                state["catalogue"] = gather_catalogue_packed(narrow, wide, d_cofp, d_index, cell_size, (TOPCELLS,) * 3)
 
         def sync():
             if world > 1:

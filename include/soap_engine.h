@@ -269,6 +269,20 @@ const double *soap_engine_table_device(const soap_engine *h);
 int32_t soap_engine_copy_table_device(soap_engine *h, double *dst_device);
 
 /*
+ * The STORED catalogue of the last run straight from the engine's table, in the caller's row order: for every output row r
+ *   out_narrow[r][k] = (float)(table[rows[r]][narrow_cols[k]] * narrow_scale[k])     k < n_narrow
+ *   out_wide[r][k]   =         table[rows[r]][wide_cols[k]]   * wide_scale[k]        k < n_wide
+ * -- the columns of the table that become datasets, multiplied by their comoving -> stored-unit factor in float64 and cast
+ * ONCE to the stored dtype (what ResultSet does on the host, SOAP/core/result_set.py:96-130 with
+ * SO_properties.py:3693-3699), in the order of the final catalogue (combine_chunks.py:38-52: `rows` is that permutation;
+ * NULL = the table's own order).  One pass over the table instead of a copy, a column gather and a row gather.
+ * Every pointer is a DEVICE pointer on cfg.device; the call returns when the outputs are complete.
+ */
+int32_t soap_engine_pack_catalogue(soap_engine *h, const int64_t *rows, int64_t n_rows,
+                                   const int32_t *narrow_cols, const double *narrow_scale, int32_t n_narrow, float *out_narrow,
+                                   const int32_t *wide_cols, const double *wide_scale, int32_t n_wide, double *out_wide);
+
+/*
  * Debug/verification entry: original particle indices (positions in the staged arrays) of
  * the particles of `type_slot` whose wrapped radius about halo row `row` satisfies
  * r < radius (strict != 0) or r <= radius (strict == 0), optionally bound-only.

@@ -14,9 +14,9 @@ for f in glob.glob(f'gpurun_out/tl_{tag}/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '')[:60], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', ''), r.get('LDS_Block_Size', '')))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith('k_estimate')]
+starts = [i for i, r in enumerate(rows) if r[2].startswith('k_estimate') or r[2].startswith('k_predict')]
 i0 = starts[-1]
-while i0 > 0 and rows[i0 - 1][2].startswith('k_predict'):
+while i0 > 0 and (rows[i0 - 1][2].startswith('k_predict') or rows[i0 - 1][2].startswith('k_estimate')):
     i0 -= 1
 t0 = rows[i0][0]
 with open(f'gpurun_out/tl_{tag}.txt', 'w') as out:

@@ -85,6 +85,11 @@ SYMBOLS = {
     ),
     "soap_engine_table_device": (C.c_void_p, [C.c_void_p]),
     "soap_engine_copy_table_device": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "soap_engine_pack_catalogue": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+         C.c_void_p],
+    ),  # fmt: skip
     "soap_engine_membership": (
         C.c_int64,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p,

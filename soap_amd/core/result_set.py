@@ -210,6 +210,24 @@ class PackedLayout:
         return narrow, wide
 
 
+    def pack_engine(self, engine, device, order=None, n_rows=None):
+        """`pack` of the table of the engine's last run without copying it out first: the engine writes the stored
+        columns, scaled and cast, straight into the two matrices -- in the row order `order` (a torch int64 tensor on the
+        device, e.g. the final-catalogue order; None = the table's own).  Same values as `pack(table)[order]` bit for bit."""
+        import torch
+
+        key = ("engine", str(device))
+        if key not in self._dev:
+            self._dev[key] = (torch.as_tensor(self.narrow_cols.astype(np.int32), device=device), torch.as_tensor(self.narrow_scale, device=device),
+                              torch.as_tensor(self.wide_cols.astype(np.int32), device=device), torch.as_tensor(self.wide_scale, device=device))
+        nc, ns, wc, ws = self._dev[key]
+        n = int(order.numel()) if order is not None else int(n_rows if n_rows is not None else engine.n_halo)
+        narrow = torch.empty((n, len(self.narrow_cols)), dtype=torch.float32, device=device)
+        wide = torch.empty((n, len(self.wide_cols)), dtype=torch.float64, device=device)
+        engine.pack_catalogue(order, nc, ns, wc, ws, narrow, wide)
+        return narrow, wide
+
+
 def _projections(hp):
     """('', 0) for ordinary calculations; ('/projx', 0), ('/projy', NC), ('/projz', 2 NC) for projected apertures
     (projected_aperture_properties.py:1891-1999: one group per projection axis)."""

@@ -245,6 +245,25 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_n;
 }
 
+// the thinned samples of a type while they are built (stage_type): append cursors, per-cell counts and the unsorted lists, per level
+struct ThinBuild {
+    unsigned *cursor;            // [2]
+    unsigned cap[2];
+    unsigned *count[2], *lc[2];
+    double *lx[2], *ly[2], *lz[2];
+};
+// ... into cell order: slot = offset of the cell + a rank from an atomic (the order inside a cell does not matter: k_predict counts)
+__global__ void k_thin_place(const unsigned *cursor, unsigned cap, const unsigned *lc, const double *lx, const double *ly, const double *lz,
+                             unsigned *off, long long ncell, unsigned *fill, double *x, double *y, double *z) {
+    const unsigned n = *cursor < cap ? *cursor : cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[ncell] = n;
+    for (unsigned s = blockIdx.x * BLK + threadIdx.x; s < n; s += gridDim.x * BLK) {
+        const unsigned c = lc[s];
+        const unsigned pos = off[c] + atomicAdd(&fill[c], 1u);
+        x[pos] = lx[s]; y[pos] = ly[s]; z[pos] = lz[s];
+    }
+}
+
 // Placement: particle i goes to slot p = offset[cell] + rank of its cell (order inside a cell is arbitrary: it only
 // feeds candidate streaming; everything order-sensitive happens after the radial sort) and its position is
 // written there (AoS input read in order -> SoA output in cell order), so no second pass has to gather the
@@ -258,7 +277,7 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
                               const double *pos, double *x, double *y, double *z,
                               Pay *pay, const void *vel_v, const void *mass_v, int value_bytes, const int *g32, const long long *g64,
-                              const long long *fof, int nu) {
+                              const long long *fof, int nu, ThinBuild thin) {
     // Velocities / Masses arrive as float64 or as float32 (what SWIFT snapshots hold, tests/dummy_halo_generator.py:806-811):
     // widened here, on the way into the payload record; every sum downstream is fp64
     const double *vel = (const double *)vel_v, *mass = (const double *)mass_v;
@@ -267,7 +286,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
     __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
-    __shared__ unsigned s_i[BLK], s_p[BLK];
+    __shared__ unsigned s_i[BLK], s_p[BLK], s_c[BLK];
     __shared__ double2 s_pay[BLK * 5];   // the block's payload records, written out as consecutive 16-byte words
     static_assert(sizeof(Pay) == 80, "payload record is five 16-byte words");
     for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
@@ -312,13 +331,29 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
         if (active) {
             unsigned li = s_off[slot] + (p - s_min[slot]);
             li = li < BLK ? li : BLK - 1;   // cannot happen with the launch contract above
-            s_x[li] = px; s_y[li] = py; s_z[li] = pz; s_i[li] = (unsigned)i; s_p[li] = p;
+            s_x[li] = px; s_y[li] = py; s_z[li] = pz; s_i[li] = (unsigned)i; s_p[li] = p; s_c[li] = c;
         }
         __syncthreads();
         if (threadIdx.x < s_total) {
             const unsigned q = s_p[threadIdx.x];
             const unsigned io = s_i[threadIdx.x];
             x[q] = s_x[threadIdx.x]; y[q] = s_y[threadIdx.x]; z[q] = s_z[threadIdx.x];
+            if (thin.cursor) {
+                // the thinned samples k_predict runs the radius loop on: appended to a list per level (with their cell), put in
+                // cell order by k_thin_place
+                const unsigned hsh = thin_hash(s_x[threadIdx.x], s_y[threadIdx.x], s_z[threadIdx.x]);
+#pragma unroll
+                for (int lv = 0; lv < 2; lv++) {
+                    if ((hsh & (lv == 0 ? 63u : 1023u)) != 0u) continue;
+                    const unsigned slot = atomicAdd(&thin.cursor[lv], 1u);
+                    if (slot < thin.cap[lv]) {
+                        const unsigned cc = s_c[threadIdx.x];
+                        thin.lc[lv][slot] = cc;
+                        thin.lx[lv][slot] = s_x[threadIdx.x]; thin.ly[lv][slot] = s_y[threadIdx.x]; thin.lz[lv][slot] = s_z[threadIdx.x];
+                        atomicAdd(&thin.count[lv][cc], 1u);
+                    }
+                }
+            }
             // the payload record of the particle (read from the block's own window of the caller's arrays)
             Pay r;
             r.x = s_x[threadIdx.x]; r.y = s_y[threadIdx.x]; r.z = s_z[threadIdx.x];
@@ -476,9 +511,11 @@ __global__ void k_estimate(const RunParams *Pp, long long *est, const double *rb
 // (first_factor x search radius) holds it.  A small central inside the envelope of a massive neighbour is different: the
 // density about it stays above the target until the sphere has grown to the neighbour's own overdensity radius -- tens of
 // rounds, a sphere of 1e5 particles for a halo of 50 -- and the work estimate of its first sphere says nothing about
-// that.  This kernel runs the loop on a THINNED copy of the particles: every PRED_STRIDE-th particle of the cell-ordered
-// coordinates (the order inside a mesh cell is the order the snapshot was written in, unrelated to position), weighted
-// with the mean particle mass of its type, binned on the ladder R_k = search_radius x 1.2^k by one wave per halo.
+// that.  This kernel runs the loop on a THINNED copy of the particles: one particle in 64 (one in 1024 for spheres of
+// millions of candidates), chosen by a hash of its coordinate bits -- a property of the particle, so the sample and with it
+// every decision taken here is the same in every run, whatever order the placement pass's atomics left the particles of a
+// cell in (the sample has its own cell-ordered copy of the coordinates, built with the mesh) -- weighted with the mean particle mass of its type,
+// counted on the ladder R_k = search_radius x 1.2^k by one wave per halo.
 // Out: the radius the first sorted superset should reach (0: the default) -- so that the sphere is selected and sorted once
 // instead of shell by shell, the halo is sent to the thread-group class of its FINAL size, and the longest chains of a
 // class start first.  A wrong guess costs time, never correctness: the halo kernels extend a superset that is too small
@@ -519,15 +556,16 @@ struct PredRows {
         nk = mk[2].count(); nj = mk[1].count();
         ntrip = nk * nj * nrun;
     }
-    // first and one-past-last cell-ordered particle of row number tl
-    __device__ __forceinline__ void row(const TypeDev &T, int tl, unsigned &beg, unsigned &end) const {
+    // first and one-past-last cell-ordered particle of row number tl (`off`: the cells' offsets -- of all particles, or of a thinned copy)
+    __device__ __forceinline__ void row(const TypeDev &T, int tl, unsigned &beg, unsigned &end) const { row_of(T.cell_offset, tl, beg, end); }
+    __device__ __forceinline__ void row_of(const unsigned *off, int tl, unsigned &beg, unsigned &end) const {
         const int rr = tl % nrun, pj = (tl / nrun) % nj, pk = tl / (nrun * nj);
         const int k = mk[2].nth(pk), j = mk[1].nth(pj);
         const long long rowbase = (long long)res * j + (long long)res * res * k;
         int rl = run_lo[0], rh = run_hi[0];
         if (rr == 1) { rl = run_lo[1]; rh = run_hi[1]; } else if (rr == 2) { rl = run_lo[2]; rh = run_hi[2]; } else if (rr == 3) { rl = run_lo[3]; rh = run_hi[3]; }
-        beg = T.cell_offset[rowbase + rl];
-        end = T.cell_offset[rowbase + rh + 1];
+        beg = off[rowbase + rl];
+        end = off[rowbase + rh + 1];
     }
 };
 // particles in the mesh cells a sphere of radius R about halo h overlaps, all staged types (what k_estimate counts); wave total
@@ -543,14 +581,14 @@ __device__ __forceinline__ long long pred_candidates(const RunParams &P, long lo
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
     return tot;
 }
-__global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_first, long long *est, int stride, int min_samples, double margin) {
-    __shared__ float s_bin[BLK / 64][PRED_K];
+__global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_first, long long *est, int min_samples, double margin, int force) {
+    __shared__ int s_ibin[BLK / 64][PRED_K];
     __shared__ double s_dens[BLK / 64][PRED_K];
     const RunParams &P = *Pp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long h = blockIdx.x * (long long)(BLK / 64) + wv;
     if (h >= P.halo.n) return;
-    float *bin = s_bin[wv];
+    int *ibin = s_ibin[wv];
     double *dens = s_dens[wv];
     const double Rs = P.halo.search_radius[h], Rread = P.halo.read_radius[h];
     const double cap = fmin(0.5 * P.boxsize, fmax(Rread, P.halo.resident ? P.halo.resident[h] : 0.0));
@@ -561,12 +599,12 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
     if (central && cap > R0 * 1.0001) {
         const double cx = P.halo.cofp[3 * h], cy = P.halo.cofp[3 * h + 1], cz = P.halo.cofp[3 * h + 2], L = P.boxsize;
         const double inv_log = 1.0 / log2(1.2);
-        bin[lane] = 0.0f;
+        double binv = 0.0;    // lane k: mass of the thinned particles (times the thinning factor) on ladder step k, all types
         double Rlo = -1.0, Rhi = R0, need = 0.0;
-        float nsamp = 0.0f;
+        int nsamp = 0;
         for (int iter = 0; iter < 8; iter++) {
-            // ---- thinned particles of the shell Rlo < r <= Rhi into the ladder bins: the mesh rows of the sphere one after
-            // the other (their cell_offset lookups 64 at a time, lanes = rows), lanes = the row's thinned particles
+            // ---- thinned particles of the shell Rlo < r <= Rhi onto the ladder: the mesh rows of the sphere one after the other
+            // (their cell_offset lookups 64 at a time, lanes = rows), lanes = 32-position words of the row's sample bitmap
             const double R2lo = Rlo < 0.0 ? -1.0 : Rlo * Rlo, R2hi = Rhi * Rhi;
             long long cand = 0;
             for (int ts = 0; ts < NT_ALL; ts++) {
@@ -580,38 +618,60 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
                 cand += tot;
                 if (ts >= SOAP_NTYPES) continue;   // (neutrinos: counted as candidates, no part of the density test)
-                unsigned st = (unsigned)stride;
-                while ((long long)st * PRED_MAXS < tot) st <<= 1;
-                const float w = (float)(T.mean_mass * (double)st);
+                const bool coarse = tot > 64ll * PRED_MAXS;
+                const int lv = coarse ? 1 : 0;
+                const unsigned *toff = T.thin_off[lv];
+                const double *tx = T.thin_x[lv], *ty = T.thin_y[lv], *tz = T.thin_z[lv];
+                ibin[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 for (int t0 = 0; t0 < rows.ntrip; t0 += 64) {
                     unsigned mybeg = 0, myend = 0;
-                    if (t0 + lane < rows.ntrip) rows.row(T, t0 + lane, mybeg, myend);
+                    if (t0 + lane < rows.ntrip) rows.row_of(toff, t0 + lane, mybeg, myend);
                     const int cnt = rows.ntrip - t0 < 64 ? rows.ntrip - t0 : 64;
-                    for (int q = 0; q < cnt; q++) {
-                        const unsigned beg = (unsigned)__builtin_amdgcn_readlane((int)mybeg, q), end = (unsigned)__builtin_amdgcn_readlane((int)myend, q);
-                        const unsigned p0 = ((beg + st - 1u) / st) * st;
-                        for (unsigned pb = p0; pb < end; pb += 64u * st) {
-                            const unsigned p = pb + (unsigned)lane * st;
-                            if (p < end) {
-                                const double ax = min_image(T.x[p], cx, L), ay = min_image(T.y[p], cy, L), az = min_image(T.z[p], cz, L);
+                    // four rows per trip: their thinned particles (lanes = particles) are requested together
+                    for (int q0 = 0; q0 < cnt; q0 += 4) {
+                        unsigned beg[4], end[4], longest = 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int q = q0 + j < cnt ? q0 + j : q0;
+                            beg[j] = (unsigned)__builtin_amdgcn_readlane((int)mybeg, q);
+                            end[j] = q0 + j < cnt ? (unsigned)__builtin_amdgcn_readlane((int)myend, q) : beg[j];
+                            longest = end[j] - beg[j] > longest ? end[j] - beg[j] : longest;
+                        }
+                        for (unsigned o = 0; o < longest; o += 64u) {
+                            double px[4], py[4], pz[4];
+                            bool have[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const unsigned p = beg[j] + o + (unsigned)lane;
+                                have[j] = p < end[j];
+                                px[j] = py[j] = pz[j] = 0.0;
+                                if (have[j]) { px[j] = tx[p]; py[j] = ty[p]; pz[j] = tz[p]; }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                if (!have[j]) continue;
+                                const double ax = min_image(px[j], cx, L), ay = min_image(py[j], cy, L), az = min_image(pz[j], cz, L);
                                 const double r2 = (ax * ax + ay * ay) + az * az;
                                 if (r2 <= R2hi && r2 > R2lo) {
                                     // smallest k with r <= Rs 1.2^k
                                     int kb = r2 > Rs * Rs ? (int)ceil(0.5 * log2(r2 / (Rs * Rs)) * inv_log) : 0;
                                     kb = kb < 0 ? 0 : (kb > PRED_K - 1 ? PRED_K - 1 : kb);
-                                    atomicAdd(&bin[kb], w);
-                                    nsamp += 1.0f;
+                                    atomicAdd(&ibin[kb], 1);
+                                    nsamp++;
                                 }
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // (integer counts per type, added in type order: the same sum whatever order the particles came in)
+                binv += (double)ibin[lane] * (T.mean_mass * (coarse ? 1024.0 : 64.0));
             }
             if (iter == 0) cand0 = cand;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // ---- the loop on the ladder: lane k holds step k
             const double Rk = Rs * exp2((double)lane * log2(1.2));
-            double M = (double)bin[lane];
+            double M = binv;
             for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(M, o, 64); if (lane >= o) M += v; }
             const bool known = Rk <= Rhi * 1.000001;      // steps the thinned sphere covers
             dens[lane] = known ? M / (4.0 / 3.0 * M_PI * Rk * Rk * Rk) : 1e300;
@@ -621,7 +681,7 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 // inside a larger one's envelope) means the loop ends inside it -- nothing to guess
                 int klast = 0;
                 for (int k = 0; k < PRED_K; k++) if (dens[k] < 1e299) klast = k;
-                if (dens[klast] <= P.target_density) break;
+                if (dens[klast] <= P.target_density && !force) break;   // (force: test hook, every halo gets a guess)
             }
             // lanes = calculations: the radius each one asks for (1e300: its density is not reached inside Rhi)
             double want = 0.0, Rso = 0.0;
@@ -653,10 +713,10 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
             Rlo = Rhi;
             Rhi = fmin(cap, fmax(2.0 * Rhi, need < 1e299 ? 1.1 * need : 0.0));
         }
-        float ns = nsamp;
+        int ns = nsamp;
         for (int o = 32; o > 0; o >>= 1) ns += __shfl_xor(ns, o, 64);
         // a guess from a handful of thinned particles is noise: such a halo keeps the default (it is small, whatever it does)
-        if (ns >= (float)min_samples && need * margin > R0) out = fmin(cap, need * margin);
+        if (ns >= min_samples && need * margin > R0) out = fmin(cap, need * margin);
     }
     // the work estimate: candidates of the first sorted superset
     long long e = out > 0.0 ? pred_candidates(P, h, out, lane) : (cand0 >= 0 ? cand0 : pred_candidates(P, h, R0, lane));
@@ -742,7 +802,14 @@ struct TypeHost {
     Pay *pay = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
     double mean_mass = 0.0;
+    unsigned *thin_off[2] = {nullptr, nullptr};
+    double *thin_xyz[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    size_t thin_cap[2] = {0, 0};
     void release(DevPool &pool) {
+        for (int lv = 0; lv < 2; lv++) {
+            pool.release(thin_off[lv], ((size_t)res * res * res + 1) * 4);
+            for (int d = 0; d < 3; d++) pool.release(thin_xyz[lv][d], thin_cap[lv] * 8);
+        }
         pool.release(pay, (size_t)n * sizeof(Pay));
         void *d8[] = {x, y, z};
         for (void *p : d8) pool.release(p, (size_t)n * 8);
@@ -1257,8 +1324,41 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         }
         HIPCHECK(hipEventCreate(&ev2));
         HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
+        ThinBuild thin;
+        memset(&thin, 0, sizeof(thin));
+        unsigned *d_tfill[2] = {nullptr, nullptr};
+        if (!nu) {
+            // thinned samples for k_predict: one particle in 64 / in 1024 by a hash of its coordinates, appended by the placement pass
+            HIPCHECK(grab((void **)&thin.cursor, 2 * sizeof(unsigned), scratch));
+            HIPCHECK(hipMemsetAsync(thin.cursor, 0, 2 * sizeof(unsigned), st));
+            for (int lv = 0; lv < 2; lv++) {
+                const size_t cap = (size_t)n / (lv == 0 ? 32 : 512) + 4096;   // (twice the expected number: the hash is uniform)
+                thin.cap[lv] = (unsigned)cap;
+                T.thin_cap[lv] = cap;
+                HIPCHECK(grab((void **)&thin.count[lv], (size_t)ncell * 4, scratch));
+                HIPCHECK(grab((void **)&d_tfill[lv], (size_t)ncell * 4, scratch));
+                HIPCHECK(grab((void **)&thin.lc[lv], cap * 4, scratch));
+                HIPCHECK(grab((void **)&thin.lx[lv], cap * 8, scratch));
+                HIPCHECK(grab((void **)&thin.ly[lv], cap * 8, scratch));
+                HIPCHECK(grab((void **)&thin.lz[lv], cap * 8, scratch));
+                HIPCHECK(hipMemsetAsync(thin.count[lv], 0, (size_t)ncell * 4, st));
+                HIPCHECK(hipMemsetAsync(d_tfill[lv], 0, (size_t)ncell * 4, st));
+                HIPCHECK(pool.alloc((void **)&T.thin_off[lv], (size_t)(ncell + 1) * 4));
+                for (int d = 0; d < 3; d++) HIPCHECK(pool.alloc((void **)&T.thin_xyz[lv][d], cap * 8));
+            }
+        }
         hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
-                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0);
+                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0, thin);
+        if (!nu) {
+            for (int lv = 0; lv < 2; lv++) {
+                hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, (const unsigned *)thin.count[lv], ncell, T.thin_off[lv], d_tilesum);
+                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
+                hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.thin_off[lv], ncell, d_tilesum, 0u);
+                hipLaunchKernelGGL(k_thin_place, dim3((unsigned)std::min<size_t>((T.thin_cap[lv] + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const unsigned *)(thin.cursor + lv), thin.cap[lv],
+                                   (const unsigned *)thin.lc[lv], (const double *)thin.lx[lv], (const double *)thin.ly[lv], (const double *)thin.lz[lv],
+                                   T.thin_off[lv], ncell, d_tfill[lv], T.thin_xyz[lv][0], T.thin_xyz[lv][1], T.thin_xyz[lv][2]);
+            }
+        }
         HIPCHECK(hipEventRecord(ev2, st));
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
@@ -1445,6 +1545,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         D.grnr32 = T.g32; D.grnr64p = T.g64; D.fof = T.fof; D.orig = T.orig; D.cell_offset = T.cell_offset; D.pay = T.pay;
         for (int d = 0; d < 3; d++) { D.pos_min[d] = T.pos_min[d]; D.pos_max[d] = T.pos_max[d]; D.cell_size[d] = T.cell_size[d]; }
         D.mean_mass = T.mean_mass;
+        for (int lv = 0; lv < 2; lv++) { D.thin_off[lv] = T.thin_off[lv]; D.thin_x[lv] = T.thin_xyz[lv][0]; D.thin_y[lv] = T.thin_xyz[lv][1]; D.thin_z[lv] = T.thin_xyz[lv][2]; }
         if (t < SOAP_NTYPES) P.soft[t] = h->cfg.softening[t];
     }
     P.halo.n = h->n_halo; P.halo.cofp = h->d_cofp; P.halo.search_radius = h->d_search; P.halo.read_radius = h->d_read;
@@ -1521,13 +1622,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         h->h_first.assign((size_t)h->n_halo, 0.0);
         h->n_predicted = 0;
-        int pred_stride = 64, pred_min = 32;
+        int pred_min = 32;
         double pred_margin = 1.0;
         if (pred) {
-            long long ntot4 = 0;
-            for (int t = 0; t < SOAP_NTYPES; t++) ntot4 += h->t[t].n;
-            pred_stride = (int)std::min<long long>(64, std::max<long long>(1, ntot4 / 262144));
-            { const char *e = getenv("SOAP_ENGINE_PRED_STRIDE"); if (e) pred_stride = std::max(1, atoi(e)); }
             { const char *e = getenv("SOAP_ENGINE_PRED_MIN"); if (e) pred_min = atoi(e); }
             { const char *e = getenv("SOAP_ENGINE_PRED_MARGIN"); if (e) pred_margin = atof(e); }
             P.halo.first_radius = h->d_first;
@@ -1536,7 +1633,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
         const unsigned gw = (unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64));
         if (pred) {
-            hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_stride, pred_min, pred_margin);
+            const int pred_force = getenv("SOAP_ENGINE_PRED_FORCE") && atoi(getenv("SOAP_ENGINE_PRED_FORCE")) != 0;
+            hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_min, pred_margin, pred_force);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(h->h_first.data(), h->d_first, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));   // (first_radius set)
@@ -1566,6 +1664,103 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         nb_small = std::min<long long>(nb_small, std::max<long long>(2048, (long long)(run_tau / 4.0e-7)));
         const double medium_cost = getenv("SOAP_ENGINE_MEDIUM_COST") ? atof(getenv("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
         nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / medium_cost)));
+    }
+    // ---- three-stage pipeline (DESIGN.md section 5.3): build the sorted superset of every halo in its arena slice
+    // (the class kernels, stage 1), run the radius loop of ALL halos with one lane per halo (stage_a.hip, stage 2), then
+    // the property passes (the class kernels again, stage 3).  Halos the pipeline cannot finish -- radius ties, bound
+    // counts that disagree with the catalogue, a loop that runs past the first superset -- fall through to the
+    // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
+    // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
+    auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
+        // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
+        // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
+        // (two equal-priority user streams get distinct hardware queues, three do not).
+        const int order[3] = {2, 1, 0};
+        for (int oi = 0; oi < 3; oi++) {
+            const int k = order[oi];
+            soap_engine::Class &C = h->cls[k];
+            hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
+            if (lists[k].empty()) continue;
+            const long long nt = (long long)lists[k].size();
+            const int nwg = (int)std::min<long long>(groups[k], nt);
+            int rc = alloc_slab(C, caps[k], groups[k]);
+            if (rc) return rc;
+            if (C.todo_cap < nt) {
+                if (C.d_todo) (void)hipFree(C.d_todo);
+                C.todo_cap = std::max<long long>(nt, 2 * h->n_halo);
+                HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
+            }
+            HIPCHECK(hipStreamWaitEvent(cs, after, 0));
+            HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
+            const RunParams *dp = h->d_params;
+            HIPCHECK(hipEventRecord(C.start, cs));
+            C.nh += nt;
+            if (!want_inertia) {
+                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+            } else {
+                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+            }
+            HIPCHECK(hipEventRecord(C.done, cs));
+            if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+        }
+        return 0;
+    };
+    bool pipeline = !want_inertia && !P.has_nu && !P.literal && !want_property_radius;
+    // SOAP_ENGINE_PIPELINE: 0 the single-kernel path for every halo; 1 the mix described below; 2 every halo through the
+    // pipeline; 3 (the default) the GIANTS through the pipeline -- halos whose sphere holds more than nb_giant candidates
+    // are built by several workgroups each (k_g* kernels) instead of keeping one 1024-thread group busy for tens of
+    // milliseconds -- and everything else on the single-kernel path, which is the fastest for the small halos (DESIGN.md 5.3)
+    int pmode = 3;
+    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); if (e) pmode = atoi(e); }
+    pipeline = pipeline && pmode != 0;
+    // Giants: the largest halo would keep a 1024-thread group busy for longer than giant_factor * tau (the
+    // multi-workgroup kernels have to find room beside the persistent groups of the other classes, which costs more
+    // than it saves unless the giants are the long pole by a clear margin: C3 and C5 on one GPU never qualify) and is
+    // large enough for the pipeline's fixed latency (~8 ms of dependent launches) to pay.  Then everything beyond the
+    // 256-thread class goes through the pipeline.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
+    long long nb_giant = 1ll << 62;
+    {
+        // (the busier the GPU, the clearer the margin has to be: beside 1e5 halos the multi-workgroup kernels wait for the
+        // persistent groups to drain -- seed 5 of the C3 box, largest halo 5.7e5 candidates: 32.7 ms with it through the
+        // pipeline, 27.8 ms without)
+        double giant_factor = 1.0 + 0.5 * std::min(1.0, std::max(0.0, (run_t_all - 10.0e-3) / 10.0e-3));
+        { const char *e = getenv("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
+        if (run_est_max * 3.8e-8 > giant_factor * run_tau && run_est_max > 2.1e5) nb_giant = nb_medium;
+        const char *e = getenv("SOAP_ENGINE_NB_GIANT");
+        if (e) nb_giant = atoll(e);
+        if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms tau %.2f ms limits %lld / %lld giants above %lld\n", run_W, run_est_max, 1e3 * run_t_all, 1e3 * run_tau, nb_small, nb_medium, nb_giant); fflush(stderr); }
+    }
+    // ---- the large halos start at once.  What comes next on the host -- the sort of 1e5 rows by estimate, the routing of the
+    // small halos, the uploads of their lists -- takes over a millisecond of a C3 pass, and the thread-group classes are the
+    // long chains of the halo phase: their rows (a few thousand: estimate above nb_small) are picked, sorted and launched
+    // first, the rest of the classification runs while they work.  Not in the modes that hand large halos to the pipeline or
+    // to teams (those decide what the classes get).
+    std::vector<int> early[3];
+    int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
+    { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
+    bool early_big = !(pipeline && (pmode == 1 || pmode == 2 || pmode == 4)) && !(pipeline && pmode == 3 && run_est_max > (double)nb_giant) && only_class < 0 &&
+                     !(getenv("SOAP_ENGINE_EARLY_BIG") && atoi(getenv("SOAP_ENGINE_EARLY_BIG")) == 0);
+    if (early_big) {
+        std::vector<std::pair<long long, int>> big;
+        for (long long i = 0; i < h->n_halo; i++) if (est[i] > nb_small) big.push_back({std::min<long long>(est[i], 0xffffffffLL), (int)i});
+        std::sort(big.begin(), big.end(), [](const std::pair<long long, int> &x, const std::pair<long long, int> &y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+        for (auto &b : big) early[b.first <= nb_medium ? 1 : 2].push_back(b.second);
+        {
+            // (room in the largest class' slab for the largest sphere and three rounds more: see the single-kernel passes below)
+            long long need = 0, n_top = (long long)early[2].size();
+            for (int i : early[2]) need = std::max(need, est[i]);
+            while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, 64))) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
+            while (caps[2] < cap_max && caps[2] < need + need / 4) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
+        }
+        HIPCHECK(hipEventRecord(h->ev_p[0], st));
+        for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
+        const int rc = launch_single(early, h->ev_p[0], false);
+        if (rc) return rc;
     }
     const auto t_host1 = std::chrono::steady_clock::now();
     // heaviest first inside every class (the reference orders by bound-particle count for the same
@@ -1600,6 +1795,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (size_t r = n; r-- > 0;) {
             const unsigned i = a[r];
             const long long nb = e32[i];
+            if (early_big && nb > nb_small) continue;   // (launched already)
             todo[nb <= nb_small ? 0 : (nb <= nb_medium ? 1 : 2)].push_back((int)i);
         }
     }
@@ -1696,51 +1892,6 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     h->ms_host_setup = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
     h->ms_host_pre = std::chrono::duration<double, std::milli>(t_host0b - t_host0).count();
     h->ms_host_classify = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
-    // ---- three-stage pipeline (DESIGN.md section 5.3): build the sorted superset of every halo in its arena slice
-    // (the class kernels, stage 1), run the radius loop of ALL halos with one lane per halo (stage_a.hip, stage 2), then
-    // the property passes (the class kernels again, stage 3).  Halos the pipeline cannot finish -- radius ties, bound
-    // counts that disagree with the catalogue, a loop that runs past the first superset -- fall through to the
-    // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
-    // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
-    auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
-        // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
-        // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
-        // (two equal-priority user streams get distinct hardware queues, three do not).
-        const int order[3] = {2, 1, 0};
-        for (int oi = 0; oi < 3; oi++) {
-            const int k = order[oi];
-            soap_engine::Class &C = h->cls[k];
-            hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
-            if (lists[k].empty()) continue;
-            const long long nt = (long long)lists[k].size();
-            const int nwg = (int)std::min<long long>(groups[k], nt);
-            int rc = alloc_slab(C, caps[k], groups[k]);
-            if (rc) return rc;
-            if (C.todo_cap < nt) {
-                if (C.d_todo) (void)hipFree(C.d_todo);
-                C.todo_cap = std::max<long long>(nt, 2 * h->n_halo);
-                HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
-            }
-            HIPCHECK(hipStreamWaitEvent(cs, after, 0));
-            HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
-            HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
-            const RunParams *dp = h->d_params;
-            HIPCHECK(hipEventRecord(C.start, cs));
-            C.nh += nt;
-            if (!want_inertia) {
-                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-                else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-                else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-            } else {
-                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-                else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-                else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
-            }
-            HIPCHECK(hipEventRecord(C.done, cs));
-            if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
-        }
-        return 0;
-    };
     int groups_small[NSV] = {256 * 11, 256 * 8, 256 * 6};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight; the 1024-entry one 25 KB of LDS: six)
     if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
@@ -1775,49 +1926,25 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
     };
-    bool pipeline = !want_inertia && !P.has_nu && !P.literal && !want_property_radius;
-    // SOAP_ENGINE_PIPELINE: 0 the single-kernel path for every halo; 1 the mix described below; 2 every halo through the
-    // pipeline; 3 (the default) the GIANTS through the pipeline -- halos whose sphere holds more than nb_giant candidates
-    // are built by several workgroups each (k_g* kernels) instead of keeping one 1024-thread group busy for tens of
-    // milliseconds -- and everything else on the single-kernel path, which is the fastest for the small halos (DESIGN.md 5.3)
-    int pmode = 3;
-    { const char *e = getenv("SOAP_ENGINE_PIPELINE"); if (e) pmode = atoi(e); }
-    pipeline = pipeline && pmode != 0;
-    // Giants: the largest halo would keep a 1024-thread group busy for longer than giant_factor * tau (the
-    // multi-workgroup kernels have to find room beside the persistent groups of the other classes, which costs more
-    // than it saves unless the giants are the long pole by a clear margin: C3 and C5 on one GPU never qualify) and is
-    // large enough for the pipeline's fixed latency (~8 ms of dependent launches) to pay.  Then everything beyond the
-    // 256-thread class goes through the pipeline.  SOAP_ENGINE_NB_GIANT fixes the limit instead.
-    long long nb_giant = 1ll << 62;
-    {
-        // (the busier the GPU, the clearer the margin has to be: beside 1e5 halos the multi-workgroup kernels wait for the
-        // persistent groups to drain -- seed 5 of the C3 box, largest halo 5.7e5 candidates: 32.7 ms with it through the
-        // pipeline, 27.8 ms without)
-        double giant_factor = 1.0 + 0.5 * std::min(1.0, std::max(0.0, (run_t_all - 10.0e-3) / 10.0e-3));
-        { const char *e = getenv("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
-        if (run_est_max * 3.8e-8 > giant_factor * run_tau && run_est_max > 2.1e5) nb_giant = nb_medium;
-        const char *e = getenv("SOAP_ENGINE_NB_GIANT");
-        if (e) nb_giant = atoll(e);
-        if (trace) { fprintf(stderr, "[soap_engine] candidates %.3g largest %.3g: t_all %.2f ms tau %.2f ms limits %lld / %lld giants above %lld\n", run_W, run_est_max, 1e3 * run_t_all, 1e3 * run_tau, nb_small, nb_medium, nb_giant); fflush(stderr); }
-    }
     h->ms_build = h->ms_stage_a = h->ms_stage_b = 0.0;
     h->n_pipeline = 0;
     h->n_gbuild = 0;
     if (trace) { fprintf(stderr, "[soap_engine] ev_p0=%p pipeline=%d st=%p\n", (void *)h->ev_p[0], (int)pipeline, (void *)st); fflush(stderr); }
-    HIPCHECK(hipEventRecord(h->ev_p[0], st));
+    if (!early_big) {
+        HIPCHECK(hipEventRecord(h->ev_p[0], st));
+        for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
+    }
     TRACE("run: ev recorded");
-    for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
     for (int v = 0; v < NSV; v++) { h->small[v].ms = 0.0; h->small[v].nh = 0; }
     h->n_small_escalated = 0;
     // Hybrid (SOAP_ENGINE_PIPELINE=1): the pipeline takes the halos of the wavefront class -- nine in ten, and what saturates the GPU on
     // the single-kernel path -- while the large halos, whose cost is a long chain in one workgroup each, start at once on
     // the single-kernel path and run beside the pipeline's stages.  SOAP_ENGINE_PIPELINE=2 sends everything down the pipeline.
-    std::vector<int> early[3];
     const bool hybrid = pipeline && pmode == 1;
     // SOAP_ENGINE_PIPELINE=4: the large halos go to TEAMS of workgroups inside one persistent launch (k_team) instead of the
     // multi-launch pipeline; everything else stays on the single-kernel path
     const bool teams = pipeline && pmode == 4;
-    if (teams) pipeline = false;
+    if (teams || early_big) pipeline = false;   // (early_big: no halo of this run is the pipeline's -- decided before the large classes were launched)
     bool giants = pipeline && pmode == 3;
     if (giants) {
         // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
@@ -1858,8 +1985,6 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
     };
-    int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
-    { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     bool small_early = false;
     if (hybrid || giants) {
         int rc = launch_single(early, h->ev_p[0], false);
@@ -2246,7 +2371,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (size_t li = 0; li < L; li++) {
             const int i = team_rows[li];
             // room for the sphere the guess reaches and for one rebuild further out (the team checks before it builds again)
-            long long c = next_pow2(std::max<long long>(est[i] + est[i] / 2, 4096));
+            long long c = next_pow2(std::max<long long>(2 * est[i], 4096));
             c = std::min<long long>(c, cap_max);
             off[i] = total; capv[i] = (int)c; total += c;
             const bool giant_sort = est[i] > giant_sort_limit;
@@ -2527,6 +2652,35 @@ int32_t soap_engine_copy_table_device(soap_engine *h, double *dst) {
     if (!h->d_table) return fail(-2, "no run to copy");
     HIPCHECK(hipSetDevice(h->cfg.device));
     HIPCHECK(hipMemcpyAsync(dst, h->d_table, (size_t)h->n_halo * h->ncols * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// one workgroup per output row: the row's stored columns, scaled and cast (soap_engine_pack_catalogue)
+__global__ void __launch_bounds__(BLK) k_pack_catalogue(const double *table, long long ncols, const long long *rows, long long n_rows,
+                                                        const int *ncol, const double *nscale, int nn, float *out_n,
+                                                        const int *wcol, const double *wscale, int nw, double *out_w) {
+    for (long long r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const double *src = table + (rows ? rows[r] : r) * ncols;
+        for (int k = threadIdx.x; k < nn; k += BLK) out_n[r * nn + k] = (float)(src[ncol[k]] * nscale[k]);
+        for (int k = threadIdx.x; k < nw; k += BLK) out_w[r * nw + k] = src[wcol[k]] * wscale[k];
+    }
+}
+
+int32_t soap_engine_pack_catalogue(soap_engine *h, const int64_t *rows, int64_t n_rows,
+                                   const int32_t *narrow_cols, const double *narrow_scale, int32_t n_narrow, float *out_narrow,
+                                   const int32_t *wide_cols, const double *wide_scale, int32_t n_wide, double *out_wide) {
+    if (!h) return fail(-1, "null handle");
+    if (!h->d_table) return fail(-2, "no run to pack");
+    if (n_rows < 0 || n_rows > h->n_halo || n_narrow < 0 || n_wide < 0) return fail(-3, "pack_catalogue: bad sizes");
+    if ((n_narrow > 0 && (!narrow_cols || !narrow_scale || !out_narrow)) || (n_wide > 0 && (!wide_cols || !wide_scale || !out_wide)))
+        return fail(-3, "pack_catalogue: null argument");
+    if (n_rows == 0) return 0;
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_pack_catalogue, dim3((unsigned)std::min<long long>(n_rows, 256 * 16)), dim3(BLK), 0, h->stream, (const double *)h->d_table,
+                       (long long)h->ncols, (const long long *)rows, (long long)n_rows, (const int *)narrow_cols, narrow_scale, (int)n_narrow, out_narrow,
+                       (const int *)wide_cols, wide_scale, (int)n_wide, out_wide);
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -67,6 +67,10 @@ struct TypeDev {
     const Pay *pay;               // payload records in cell order
     double pos_min[3], pos_max[3], cell_size[3];
     double mean_mass;             // of a thinned sample of the type's particles (the scheduling guess of k_predict)
+    // thinned copies of the type's particles for k_predict, levels 0 / 1 = one particle in 64 / in 1024 (chosen by thin_hash of its
+    // coordinates): coordinates in mesh-cell order and the cells' offsets into them
+    const unsigned *thin_off[2];
+    const double *thin_x[2], *thin_y[2], *thin_z[2];
 };
 
 struct SlabDev {
@@ -425,8 +429,21 @@ struct TypeG {   // same layout as TypeDev, pointers typed as global
     const GAS Pay *pay;
     double pos_min[3], pos_max[3], cell_size[3];
     double mean_mass;
+    const GAS unsigned *thin_off[2];
+    const GAS double *thin_x[2], *thin_y[2], *thin_z[2];
 };
 static_assert(sizeof(TypeG) == sizeof(TypeDev), "TypeG mirrors TypeDev");
+
+// Is the particle at (x, y, z) in the thinned sample?  A hash of the coordinate bits: a property of the particle, not of where the
+// placement pass put it inside its cell (that order comes out of atomics and differs from run to run).  Returns the hash; the
+// sample 1-in-64 is (h & 63) == 0, 1-in-1024 (h & 1023) == 0.
+SOAP_DEV unsigned thin_hash(double x, double y, double z) {
+    unsigned long long h = (unsigned long long)__double_as_longlong(x) * 0x9E3779B97F4A7C15ull;
+    h ^= (unsigned long long)__double_as_longlong(y) * 0xC2B2AE3D27D4EB4Full;
+    h ^= (unsigned long long)__double_as_longlong(z) * 0x165667B19E3779F9ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return (unsigned)h;
+}
 
 // one payload record from global memory (field by field: the compiler merges them into 16-byte loads)
 SOAP_DEV Pay load_pay(const GAS Pay *p) {

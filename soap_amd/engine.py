@@ -294,6 +294,16 @@ class Engine:
             raise ValueError("need a CUDA float64 tensor of n_halo*row_columns elements")
         self._check(self._lib.soap_engine_copy_table_device(self._h, C.c_void_p(tensor.data_ptr())))
 
+    def pack_catalogue(self, rows, narrow_cols, narrow_scale, wide_cols, wide_scale, out_narrow, out_wide):
+        """Stored catalogue of the last run from the engine's table in ONE pass (soap_engine_pack_catalogue): torch CUDA
+        tensors -- rows int64 [n] or None, *_cols int32, *_scale float64, out_narrow float32 [n, Nn], out_wide float64 [n, Nw]."""
+        n = int(out_narrow.shape[0])
+        self._order_after_torch(out_narrow)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None  # noqa: E731
+        self._check(self._lib.soap_engine_pack_catalogue(
+            self._h, ptr(rows), n, ptr(narrow_cols), ptr(narrow_scale), int(narrow_cols.numel()), ptr(out_narrow),
+            ptr(wide_cols), ptr(wide_scale), int(wide_cols.numel()), ptr(out_wide)))
+
     def table_device_ptr(self):
         return self._lib.soap_engine_table_device(self._h)
 

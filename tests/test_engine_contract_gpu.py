@@ -272,3 +272,74 @@ def test_runs_the_pipeline_cannot_serve_stay_on_the_single_kernel_path(built_lib
     t2, s2, n2 = run()
     assert n0 == 0 and n2 == 0
     assert np.array_equal(s0, s2) and np.array_equal(t0, t2)
+
+
+def test_stored_catalogue_packed_by_the_engine_equals_the_host_rule(built_library):
+    """soap_engine_pack_catalogue: the stored columns of the result table, scaled and cast once, in the caller's row order,
+    written by ONE pass over the engine's table -- bit for bit what PackedLayout.pack does with a copy of the table
+    (SOAP/core/result_set.py:96-130 and SO_properties.py:3693-3699 restated) followed by a row gather."""
+    import torch
+
+    from soap_amd.core.result_set import PackedLayout
+
+    sc, data, halos = make_chunk(120000, 80, seed=31, hydro=True)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=False)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)), projected_vars=chp.projected_variations((50.0,)))
+    engine = halo_tasks.make_engine(sc, device=0)
+    halo_tasks.stage_chunk(engine, data_np)
+    H = len(halos_np["index"])
+    ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
+    halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False)
+    table = torch.as_tensor(engine.fetch(table=True)["table"], device="cuda:0")
+    packed = PackedLayout(props, engine.desc_columns)
+    narrow, wide = packed.pack(table)
+    order = torch.randperm(H, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
+    n2, w2 = packed.pack_engine(engine, "cuda:0", order=order)
+    assert n2.dtype == torch.float32 and w2.dtype == torch.float64 and n2.shape == (H, narrow.shape[1]) and w2.shape == (H, wide.shape[1])
+    assert torch.equal(n2, narrow[order]) and torch.equal(w2, wide[order])
+    n3, w3 = packed.pack_engine(engine, "cuda:0", order=None)
+    assert torch.equal(n3, narrow) and torch.equal(w3, wide)
+    sub = order[: H // 3].contiguous()
+    n4, w4 = packed.pack_engine(engine, "cuda:0", order=sub)
+    assert torch.equal(n4, narrow[sub]) and torch.equal(w4, wide[sub])
+    engine.close()
+
+
+def test_the_scheduling_guess_changes_no_result(built_library, monkeypatch):
+    """k_predict guesses, from a thinned copy of the particles, where a halo's radius loop will end; the first sorted superset,
+    the thread-group class and the launch order follow the guess.  Whatever it says -- here it is made to speak up for every
+    halo with at least one thinned particle -- selections, radius rounds, radii and statuses are those of a run without it
+    and the values agree to rounding (another class sums in another order); and it says the same in every run."""
+    sc, data, halos = make_chunk(300000, 200, seed=61, read_radius_factor=8.0, halo_fraction=0.7)
+    data_np, halos_np = to_numpy(data, halos)
+    cf = CategoryFilter(dmo=True)
+    props = chp.build_halo_prop_list(sc, cf, None, chp.aperture_variations((30.0, 100.0)))
+    H = len(halos_np["index"])
+    engine = halo_tasks.make_engine(sc, device=0)
+
+    def run(predict, pred_min=None):
+        monkeypatch.setenv("SOAP_ENGINE_PREDICT", "1" if predict else "0")
+        monkeypatch.setenv("SOAP_ENGINE_PRED_FORCE", "1")   # (the halos of this box are isolated: none would get a guess by itself)
+        monkeypatch.setenv("SOAP_ENGINE_PRED_MARGIN", "1.5")
+        if pred_min is None:
+            monkeypatch.delenv("SOAP_ENGINE_PRED_MIN", raising=False)
+        else:
+            monkeypatch.setenv("SOAP_ENGINE_PRED_MIN", str(pred_min))
+        halo_tasks.stage_chunk(engine, data_np)
+        ha = dict({k: v.copy() for k, v in halos_np.items()}, done=np.zeros(H, dtype=np.int32))
+        out = halo_tasks.process_halos(engine, props, sc, ha, None, unpack=False, resident_radius=np.inf)
+        return ha, out[4], engine.fetch(table=True)["table"], int(engine.kernel_ms("n_predicted"))
+
+    ha0, raw0, t0, np0 = run(False)
+    ha1, raw1, t1, np1 = run(True, pred_min=1)
+    ha2, raw2, t2, np2 = run(True, pred_min=1)
+    assert np0 == 0 and np1 > 0 and np2 == np1
+    for ha, raw in ((ha1, raw1), (ha2, raw2)):
+        assert np.array_equal(raw["status"], raw0["status"]) and np.array_equal(ha["done"], ha0["done"])
+        assert np.array_equal(raw["stats"][:, [0, 1, 4, 5]], raw0["stats"][:, [0, 1, 4, 5]])   # rounds, sphere content, rounds of all attempts, attempts
+        assert np.array_equal(ha["search_radius"], ha0["search_radius"]) and np.array_equal(ha["read_radius"], ha0["read_radius"])
+    scale = np.maximum(np.abs(t0).max(axis=0, keepdims=True), 1e-300)
+    assert np.all(np.abs(t1 - t0) <= 1e-11 * np.abs(t0) + 1e-13 * scale)
+    assert np.array_equal(t1, t2)   # the same guess, the same classes, the same sums: bit for bit
+    engine.close()

@@ -271,7 +271,7 @@ def test_teams_equal_the_single_kernel_path(built_library, monkeypatch, hydro, s
     ha1, res1, raw1, t1, _ = _run(engine, props, sc, halos_np, pipeline=False, resident=resident)
     ha2, res2, raw2, t2, _ = _run(engine, props, sc, halos_np, pipeline=4, resident=resident)
     n_team, n_failed = engine.kernel_ms("n_team"), engine.kernel_ms("n_team_failed")
-    assert n_team > 0.2 * len(halos_np["index"]) and n_failed <= 0.1 * n_team, (n_team, n_failed)
+    assert n_team > 0.2 * len(halos_np["index"]) and n_failed <= 0.3 * n_team, (n_team, n_failed)   # (a sphere that outgrows its arena slice is left to the single-kernel path)
     assert np.array_equal(raw1["status"], raw2["status"]) and np.array_equal(ha1["done"], ha2["done"])
     assert np.array_equal(ha1["read_radius"], ha2["read_radius"]) and np.array_equal(ha1["search_radius"], ha2["search_radius"])
     assert np.array_equal(raw1["stats"][:, [0, 1, 2, 4, 5]], raw2["stats"][:, [0, 1, 2, 4, 5]])
