@@ -247,20 +247,23 @@ __global__ void k_scan_add(unsigned *out, long long n, const unsigned *tilesum, 
 
 // the thinned samples of a type while they are built (stage_type): append cursors, per-cell counts and the unsorted lists, per level
 struct ThinBuild {
-    unsigned *cursor;            // [2]
-    unsigned cap[2];
+    unsigned *cursor;            // [blocks of the placement pass][2]: entries of the block's sub-list, per level
+    unsigned cap[2];             // entries a sub-list holds, per level
     unsigned *count[2], *lc[2];
     double *lx[2], *ly[2], *lz[2];
 };
 // ... into cell order: slot = offset of the cell + a rank from an atomic (the order inside a cell does not matter: k_predict counts)
-__global__ void k_thin_place(const unsigned *cursor, unsigned cap, const unsigned *lc, const double *lx, const double *ly, const double *lz,
-                             unsigned *off, long long ncell, unsigned *fill, double *x, double *y, double *z) {
-    const unsigned n = *cursor < cap ? *cursor : cap;
-    if (blockIdx.x == 0 && threadIdx.x == 0) off[ncell] = n;
-    for (unsigned s = blockIdx.x * BLK + threadIdx.x; s < n; s += gridDim.x * BLK) {
-        const unsigned c = lc[s];
-        const unsigned pos = off[c] + atomicAdd(&fill[c], 1u);
-        x[pos] = lx[s]; y[pos] = ly[s]; z[pos] = lz[s];
+__global__ void k_thin_place(const unsigned *cursor, int lv, unsigned cap, int nsub, const unsigned *lc, const double *lx, const double *ly, const double *lz,
+                             unsigned *off, long long ncell, const unsigned *count, unsigned *fill, double *x, double *y, double *z) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[ncell] = off[ncell - 1] + count[ncell - 1];
+    for (int sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
+        const unsigned n = cursor[2 * sub + lv];
+        for (unsigned e = threadIdx.x; e < n; e += BLK) {
+            const unsigned s = (unsigned)sub * cap + e;
+            const unsigned c = lc[s];
+            const unsigned pos = off[c] + atomicAdd(&fill[c], 1u);
+            x[pos] = lx[s]; y[pos] = ly[s]; z[pos] = lz[s];
+        }
     }
 }
 
@@ -287,9 +290,11 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
     __shared__ unsigned s_i[BLK], s_p[BLK], s_c[BLK];
+    __shared__ unsigned s_thin_n[2];   // this block's thinned particles so far, per level (its own sub-list: no global cursor)
     __shared__ double2 s_pay[BLK * 5];   // the block's payload records, written out as consecutive 16-byte words
     static_assert(sizeof(Pay) == 80, "payload record is five 16-byte words");
     for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
+    if (threadIdx.x < 2) s_thin_n[threadIdx.x] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long stride = (long long)gridDim.x * BLK;
@@ -345,8 +350,9 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
 #pragma unroll
                 for (int lv = 0; lv < 2; lv++) {
                     if ((hsh & (lv == 0 ? 63u : 1023u)) != 0u) continue;
-                    const unsigned slot = atomicAdd(&thin.cursor[lv], 1u);
-                    if (slot < thin.cap[lv]) {
+                    const unsigned local = atomicAdd(&s_thin_n[lv], 1u);   // (LDS: the sub-list belongs to this block)
+                    if (local < thin.cap[lv]) {
+                        const unsigned slot = blockIdx.x * thin.cap[lv] + local;
                         const unsigned cc = s_c[threadIdx.x];
                         thin.lc[lv][slot] = cc;
                         thin.lx[lv][slot] = s_x[threadIdx.x]; thin.ly[lv][slot] = s_y[threadIdx.x]; thin.lz[lv][slot] = s_z[threadIdx.x];
@@ -384,6 +390,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
         for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
         __syncthreads();
     }
+    if (thin.cursor && threadIdx.x < 2) thin.cursor[2 * blockIdx.x + threadIdx.x] = s_thin_n[threadIdx.x] < thin.cap[threadIdx.x] ? s_thin_n[threadIdx.x] : thin.cap[threadIdx.x];
 }
 
 // ---- the per-halo kernels live in halo_class.hip, one translation unit per thread-group class and variant
@@ -594,9 +601,13 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
     const double cap = fmin(0.5 * P.boxsize, fmax(Rread, P.halo.resident ? P.halo.resident[h] : 0.0));
     const double R0 = fmin(Rread, Rs * P.first_factor);
     double out = 0.0;
-    long long cand0 = -1;
+    // Only a halo whose first sphere holds many times its own bound particles can be inside another's envelope: everybody else
+    // keeps the estimate k_estimate left (this kernel needs three times its registers: it runs for the suspects only)
+    const long long cand0 = est[h];
+    const bool suspect = force || cand0 > 8ll * (long long)P.halo.nr_bound[h] + 2048ll;
     const bool central = P.halo.is_central[h] == 1 && P.target_density > 0.0;
-    if (central && cap > R0 * 1.0001) {
+    if (!suspect || !central) { if (lane == 0) r_first[h] = 0.0; return; }
+    if (cap > R0 * 1.0001) {
         const double cx = P.halo.cofp[3 * h], cy = P.halo.cofp[3 * h + 1], cz = P.halo.cofp[3 * h + 2], L = P.boxsize;
         const double inv_log = 1.0 / log2(1.2);
         double binv = 0.0;    // lane k: mass of the thinned particles (times the thinning factor) on ladder step k, all types
@@ -668,7 +679,7 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 // (integer counts per type, added in type order: the same sum whatever order the particles came in)
                 binv += (double)ibin[lane] * (T.mean_mass * (coarse ? 1024.0 : 64.0));
             }
-            if (iter == 0) cand0 = cand;
+            (void)cand;
             // ---- the loop on the ladder: lane k holds step k
             const double Rk = Rs * exp2((double)lane * log2(1.2));
             double M = binv;
@@ -719,7 +730,7 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
         if (ns >= min_samples && need * margin > R0) out = fmin(cap, need * margin);
     }
     // the work estimate: candidates of the first sorted superset
-    long long e = out > 0.0 ? pred_candidates(P, h, out, lane) : (cand0 >= 0 ? cand0 : pred_candidates(P, h, R0, lane));
+    const long long e = out > 0.0 ? pred_candidates(P, h, out, lane) : cand0;
     if (lane == 0) { r_first[h] = out; est[h] = e; }
 }
 
@@ -1327,13 +1338,15 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         ThinBuild thin;
         memset(&thin, 0, sizeof(thin));
         unsigned *d_tfill[2] = {nullptr, nullptr};
-        if (!nu) {
+        const bool want_thin = !nu && !(getenv("SOAP_ENGINE_THIN") && atoi(getenv("SOAP_ENGINE_THIN")) == 0);
+        if (want_thin) {
             // thinned samples for k_predict: one particle in 64 / in 1024 by a hash of its coordinates, appended by the placement pass
-            HIPCHECK(grab((void **)&thin.cursor, 2 * sizeof(unsigned), scratch));
-            HIPCHECK(hipMemsetAsync(thin.cursor, 0, 2 * sizeof(unsigned), st));
+            HIPCHECK(grab((void **)&thin.cursor, (size_t)grid * 2 * sizeof(unsigned), scratch));
             for (int lv = 0; lv < 2; lv++) {
-                const size_t cap = (size_t)n / (lv == 0 ? 32 : 512) + 4096;   // (twice the expected number: the hash is uniform)
-                thin.cap[lv] = (unsigned)cap;
+                // every block of the placement pass appends to a sub-list of its own: twice what it expects (the hash is uniform) and some
+                const size_t sub = (size_t)n / (size_t)grid / (lv == 0 ? 32 : 512) + 256;
+                const size_t cap = sub * (size_t)grid;
+                thin.cap[lv] = (unsigned)sub;
                 T.thin_cap[lv] = cap;
                 HIPCHECK(grab((void **)&thin.count[lv], (size_t)ncell * 4, scratch));
                 HIPCHECK(grab((void **)&d_tfill[lv], (size_t)ncell * 4, scratch));
@@ -1349,14 +1362,14 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         }
         hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
                            dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0, thin);
-        if (!nu) {
+        if (want_thin) {
             for (int lv = 0; lv < 2; lv++) {
                 hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, (const unsigned *)thin.count[lv], ncell, T.thin_off[lv], d_tilesum);
                 hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, st, d_tilesum, ntiles);
                 hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(BLK), 0, st, T.thin_off[lv], ncell, d_tilesum, 0u);
-                hipLaunchKernelGGL(k_thin_place, dim3((unsigned)std::min<size_t>((T.thin_cap[lv] + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, (const unsigned *)(thin.cursor + lv), thin.cap[lv],
+                hipLaunchKernelGGL(k_thin_place, dim3((unsigned)grid), dim3(BLK), 0, st, (const unsigned *)thin.cursor, lv, thin.cap[lv], grid,
                                    (const unsigned *)thin.lc[lv], (const double *)thin.lx[lv], (const double *)thin.ly[lv], (const double *)thin.lz[lv],
-                                   T.thin_off[lv], ncell, d_tfill[lv], T.thin_xyz[lv][0], T.thin_xyz[lv][1], T.thin_xyz[lv][2]);
+                                   T.thin_off[lv], ncell, (const unsigned *)thin.count[lv], d_tfill[lv], T.thin_xyz[lv][0], T.thin_xyz[lv][1], T.thin_xyz[lv][2]);
             }
         }
         HIPCHECK(hipEventRecord(ev2, st));
@@ -1614,6 +1627,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // the work estimate the classes, the launch order and the slab sizes go by
         int pred = (P.literal || h->cfg.slab_capacity > 0) ? 0 : 1;
         { const char *e = getenv("SOAP_ENGINE_PREDICT"); if (e) pred = atoi(e); }
+        for (int t = 0; t < SOAP_NTYPES; t++) if (h->t[t].n > 0 && !h->t[t].thin_off[0]) pred = 0;   // (staged without the thinned copies)
         if (h->first_count < (size_t)h->n_halo) {
             if (h->d_first) (void)hipFree(h->d_first);
             h->d_first = nullptr;
@@ -1632,14 +1646,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         long long *d_est;
         HIPCHECK(h->pool.alloc((void **)&d_est, (size_t)h->n_halo * 8));
         const unsigned gw = (unsigned)((h->n_halo + BLK / 64 - 1) / (BLK / 64));
+        hipLaunchKernelGGL(k_estimate, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
         if (pred) {
             const int pred_force = getenv("SOAP_ENGINE_PRED_FORCE") && atoi(getenv("SOAP_ENGINE_PRED_FORCE")) != 0;
             hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_min, pred_margin, pred_force);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(h->h_first.data(), h->d_first, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));   // (first_radius set)
-        } else {
-            hipLaunchKernelGGL(k_estimate, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
         }
         HIPCHECK(hipMemcpyAsync(est.data(), d_est, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
