@@ -448,7 +448,10 @@ def main():
 
     def halo_counts(engine):
         return {
-            "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single"))},
+            "halos_by_path": {"pipeline": int(engine.kernel_ms("n_pipeline")), "single_kernel": int(engine.kernel_ms("n_single")),
+                              "teams": int(engine.kernel_ms("n_team"))},
+            # halos whose first sorted superset, class and place in the launch order follow k_predict's guess of where their radius loop ends
+            "halos_with_a_radius_guess": int(engine.kernel_ms("n_predicted")),
             "single_kernel_passes": int(engine.kernel_ms("n_passes")),   # more than 1: a halo outgrew its slab and was done again
             "halos_per_class": [int(engine.kernel_ms("n_wave")), int(engine.kernel_ms("n_wg256")),
                                 int(engine.kernel_ms("n_wg1024"))],
@@ -489,7 +492,7 @@ def main():
         # bench): only quoted when the workload is the one that was profiled
         traffic = None
         tnote = "no PMC profile of this workload committed"
-        for prof in ("round3", "round2", "round1"):
+        for prof in ("round4", "round3", "round2", "round1"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof, "final_c3_hbm_traffic.json")) as f:
                     pj = json.load(f)

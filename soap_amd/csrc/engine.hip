@@ -414,8 +414,8 @@ void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev are
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
                         const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
 void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart);
-void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int teams, int K, int split,
-                      const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
+void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int groups, int split,
+                      long long ntiles, long long ngblocks, long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
                       const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan);
 }
 
@@ -2365,10 +2365,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (!team_rows.empty()) {
         const size_t n = (size_t)h->n_halo, L = team_rows.size();
         team_scratch.L = L;
-        int K = 4, T = 32;
-        { const char *e = getenv("SOAP_ENGINE_TEAM_K"); if (e) K = std::max(1, std::min(16, atoi(e))); }
+        // workgroups of the launch (one per CU: the kernel's LDS): all of them walk every phase together
+        int T = 128;
         { const char *e = getenv("SOAP_ENGINE_TEAMS"); if (e) T = atoi(e); }
-        T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(T, TEAM_MAX), (long long)L));
+        T = std::max(1, std::min(T, 256));
         if (h->hdr_bytes < n * sizeof(HaloHdr)) {
             if (h->d_hdr) (void)hipFree(h->d_hdr);
             h->d_hdr = nullptr;
@@ -2463,13 +2463,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
         double *bpart = use_bpartials ? h->d_bpart[0] : nullptr;
         HIPCHECK(hipEventRecord(h->team_start, ts));
-        soap_launch_team(ts, h->d_params_pipe, h->arena, h->d_teamctl, (long long)L, T, K, split, dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8],
-                         dptr[10], dptr[11], bpart, bpart ? bpart + ntiles_total * 2 * NACC : nullptr);
+        soap_launch_team(ts, h->d_params_pipe, h->arena, h->d_teamctl, (long long)L, T, split, (long long)tile_li.size(), (long long)gblock_li.size(), (long long)sel_li.size(),
+                         dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8], dptr[10], dptr[11], bpart, bpart ? bpart + ntiles_total * 2 * NACC : nullptr);
         hipLaunchKernelGGL(k_team_states, dim3((unsigned)std::min<size_t>((L + BLK - 1) / BLK, 256)), dim3(BLK), 0, ts, (const HaloHdr *)h->d_hdr, (const int *)dptr[0], (long long)L, d_tstate);
         HIPCHECK(hipEventRecord(h->team_done, ts));
         HIPCHECK(hipGetLastError());
         h->n_team = (long long)L;
-        if (trace) { fprintf(stderr, "[soap_engine] teams: %zu halos above %lld candidates (largest %lld), %d teams of %d groups, arena %lld entries, %zu tiles\n", L, (long long)est[team_rows.back()], (long long)est[team_rows[0]], T, K, total, ntiles_total); fflush(stderr); }
+        if (trace) { fprintf(stderr, "[soap_engine] teams: %zu halos above %lld candidates (largest %lld), %d workgroups, arena %lld entries, %zu tiles\n", L, (long long)est[team_rows.back()], (long long)est[team_rows[0]], T, total, ntiles_total); fflush(stderr); }
     }
     TRACE("run: single-kernel part");
     h->n_single = (long long)(todo[0].size() + todo[1].size() + todo[2].size() + early[0].size() + early[1].size() + early[2].size() + todo_small[0].size() + todo_small[1].size() + todo_small[2].size());

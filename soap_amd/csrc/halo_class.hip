@@ -97,12 +97,13 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
 // records of the large halos of a team run (k_ginit), then the team kernel: T teams of K workgroups, one persistent launch
-extern "C" void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int teams, int K, int split,
+extern "C" void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int groups, int split,
+                                 long long ntiles, long long ngblocks, long long nselparts,
                                  const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
                                  const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan) {
-    if (nlarge <= 0 || teams <= 0) return;
+    if (nlarge <= 0 || groups <= 0) return;
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((nlarge + 63) / 64)), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, bin_first, nbin);
-    hipLaunchKernelGGL(k_team, dim3((unsigned)(teams * K)), dim3(GRP), 0, stream, params, arena, ctl, nlarge, K, split, bpart, bscan);
+    hipLaunchKernelGGL(k_team, dim3((unsigned)groups), dim3(GRP), 0, stream, params, arena, ctl, nlarge, 0, split, bpart, bscan, ntiles, ngblocks, nselparts);
 }
 // tile sums for the property stage of the large halos whose radius loop has finished (k_bpartials)
 extern "C" void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart) {

@@ -245,16 +245,16 @@ def test_more_than_32_so_thresholds_through_the_tile_parallel_build(built_librar
     engine.close()
 
 
-@pytest.mark.parametrize("hydro,seed,read_factor,nb_team,team_k,giant_sort",
-                         [(False, 51, 8.0, 600, 4, None), (True, 52, 1.5, 2000, 3, None), (False, 53, 1.5, 600, 2, 3000), (False, 54, 8.0, 600, 1, None)])
-def test_teams_equal_the_single_kernel_path(built_library, monkeypatch, hydro, seed, read_factor, nb_team, team_k, giant_sort):
-    """SOAP_ENGINE_PIPELINE=4: the halos beyond nb_team candidates are done by TEAMS of workgroups inside one persistent
-    launch (k_team: the phases of the tile-parallel build, the one-lane radius loop, rebuilds further out, tile sums, the
-    property passes, with a team barrier between them) beside the single-kernel path of the others.  Same sorted slabs, same
-    property passes: the table of the single-kernel path bit for bit (tile sums off), to rounding with them."""
+@pytest.mark.parametrize("hydro,seed,read_factor,nb_team,groups,giant_sort",
+                         [(False, 51, 8.0, 600, 24, None), (True, 52, 1.5, 2000, 7, None), (False, 53, 1.5, 600, 16, 3000), (False, 54, 8.0, 600, 1, None)])
+def test_teams_equal_the_single_kernel_path(built_library, monkeypatch, hydro, seed, read_factor, nb_team, groups, giant_sort):
+    """SOAP_ENGINE_PIPELINE=4: the halos beyond nb_team candidates are done by the workgroups of ONE persistent launch
+    (k_team: the phases of the tile-parallel build over all of them, the radius loops with lanes = halos, rebuilds further out,
+    tile sums, the property passes, a grid barrier between the phases) beside the single-kernel path of the others.  Same
+    sorted slabs, same property passes: the table of the single-kernel path bit for bit (tile sums off), to rounding with them;
+    whatever the number of workgroups (1: every phase of every halo by one group)."""
     monkeypatch.setenv("SOAP_ENGINE_NB_TEAM", str(nb_team))
-    monkeypatch.setenv("SOAP_ENGINE_TEAM_K", str(team_k))
-    monkeypatch.setenv("SOAP_ENGINE_TEAMS", "6")
+    monkeypatch.setenv("SOAP_ENGINE_TEAMS", str(groups))
     monkeypatch.setenv("SOAP_ENGINE_NB_SMALL", str(nb_team // 2))   # (the 256-thread class on the single-kernel side for the same halos)
     if giant_sort is not None:
         monkeypatch.setenv("SOAP_ENGINE_GIANT_SORT", str(giant_sort))
