@@ -277,6 +277,9 @@ __global__ void k_thin_place(const unsigned *cursor, int lv, unsigned cap, int n
 // destination run in LDS (hash table: run start and length per cell, prefix over the table), then consecutive
 // threads store to consecutive addresses -- four coalesced streams instead of four scattered 8-byte stores
 // per particle.  Launched with the grid of k_cellid (same particles per block iteration).
+// (NARROW / THIN are template parameters: a run-time select between the float32 and the float64 load made the compiler issue both,
+// and the pass 0.8 ms slower on 1e8 particles)
+template <bool NARROW, bool THIN>
 __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long long n, const unsigned *offset,
                               const double *pos, double *x, double *y, double *z,
                               Pay *pay, const void *vel_v, const void *mass_v, int value_bytes, const int *g32, const long long *g64,
@@ -285,7 +288,8 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
     // widened here, on the way into the payload record; every sum downstream is fp64
     const double *vel = (const double *)vel_v, *mass = (const double *)mass_v;
     const float *vel4 = (const float *)vel_v, *mass4 = (const float *)mass_v;
-    const bool narrow = value_bytes == 4;
+    constexpr bool narrow = NARROW;
+    (void)value_bytes;
     __shared__ unsigned s_key[CELL_SLOTS], s_cnt[CELL_SLOTS], s_min[CELL_SLOTS], s_off[CELL_SLOTS];
     __shared__ unsigned s_wsum[BLK / 64], s_total;
     __shared__ double s_x[BLK], s_y[BLK], s_z[BLK];
@@ -343,7 +347,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
             const unsigned q = s_p[threadIdx.x];
             const unsigned io = s_i[threadIdx.x];
             x[q] = s_x[threadIdx.x]; y[q] = s_y[threadIdx.x]; z[q] = s_z[threadIdx.x];
-            if (thin.cursor) {
+            if constexpr (THIN) {
                 // the thinned samples k_predict runs the radius loop on: appended to a list per level (with their cell), put in
                 // cell order by k_thin_place
                 const unsigned hsh = thin_hash(s_x[threadIdx.x], s_y[threadIdx.x], s_z[threadIdx.x]);
@@ -363,11 +367,12 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
             // the payload record of the particle (read from the block's own window of the caller's arrays)
             Pay r;
             r.x = s_x[threadIdx.x]; r.y = s_y[threadIdx.x]; r.z = s_z[threadIdx.x];
-            r.m = narrow ? (double)mass4[io] : mass[io];
-            if (nu) { r.vx = narrow ? (double)vel4[io] : vel[io]; r.vy = 0.0; r.vz = 0.0; r.grnr = -1; r.fof = -1; }
+            if constexpr (narrow) r.m = (double)mass4[io]; else r.m = mass[io];
+            if (nu) { if constexpr (narrow) r.vx = (double)vel4[io]; else r.vx = vel[io]; r.vy = 0.0; r.vz = 0.0; r.grnr = -1; r.fof = -1; }
             else {
                 const long long v0 = 3 * (long long)io;
-                r.vx = narrow ? (double)vel4[v0] : vel[v0]; r.vy = narrow ? (double)vel4[v0 + 1] : vel[v0 + 1]; r.vz = narrow ? (double)vel4[v0 + 2] : vel[v0 + 2];
+                if constexpr (narrow) { r.vx = (double)vel4[v0]; r.vy = (double)vel4[v0 + 1]; r.vz = (double)vel4[v0 + 2]; }
+                else { r.vx = vel[v0]; r.vy = vel[v0 + 1]; r.vz = vel[v0 + 2]; }
                 r.grnr = g64 ? g64[io] : (long long)g32[io];
                 r.fof = fof[io];
             }
@@ -390,7 +395,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
         for (int t = threadIdx.x; t < CELL_SLOTS; t += BLK) { s_key[t] = CELL_EMPTY; s_cnt[t] = 0u; s_min[t] = 0xffffffffu; }
         __syncthreads();
     }
-    if (thin.cursor && threadIdx.x < 2) thin.cursor[2 * blockIdx.x + threadIdx.x] = s_thin_n[threadIdx.x] < thin.cap[threadIdx.x] ? s_thin_n[threadIdx.x] : thin.cap[threadIdx.x];
+    if (THIN && threadIdx.x < 2) thin.cursor[2 * blockIdx.x + threadIdx.x] = s_thin_n[threadIdx.x] < thin.cap[threadIdx.x] ? s_thin_n[threadIdx.x] : thin.cap[threadIdx.x];
 }
 
 // ---- the per-halo kernels live in halo_class.hip, one translation unit per thread-group class and variant
@@ -1360,8 +1365,15 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
                 for (int d = 0; d < 3; d++) HIPCHECK(pool.alloc((void **)&T.thin_xyz[lv][d], cap * 8));
             }
         }
-        hipLaunchKernelGGL(k_scatter_pos, dim3(grid), dim3(BLK), 0, st, d_cell, d_rank, (long long)n, T.cell_offset,
-                           dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0, thin);
+#define SCATTER_ARGS d_cell, d_rank, (long long)n, T.cell_offset, dpos, T.x, T.y, T.z, T.pay, t_vel, t_mass, t_vbytes, t_g32, t_g64, t_fof, nu ? 1 : 0, thin
+        if (t_vbytes == 4) {
+            if (want_thin) hipLaunchKernelGGL((k_scatter_pos<true, true>), dim3(grid), dim3(BLK), 0, st, SCATTER_ARGS);
+            else hipLaunchKernelGGL((k_scatter_pos<true, false>), dim3(grid), dim3(BLK), 0, st, SCATTER_ARGS);
+        } else {
+            if (want_thin) hipLaunchKernelGGL((k_scatter_pos<false, true>), dim3(grid), dim3(BLK), 0, st, SCATTER_ARGS);
+            else hipLaunchKernelGGL((k_scatter_pos<false, false>), dim3(grid), dim3(BLK), 0, st, SCATTER_ARGS);
+        }
+#undef SCATTER_ARGS
         if (want_thin) {
             for (int lv = 0; lv < 2; lv++) {
                 hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, st, (const unsigned *)thin.count[lv], ncell, T.thin_off[lv], d_tilesum);

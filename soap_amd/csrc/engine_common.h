@@ -438,11 +438,13 @@ static_assert(sizeof(TypeG) == sizeof(TypeDev), "TypeG mirrors TypeDev");
 // placement pass put it inside its cell (that order comes out of atomics and differs from run to run).  Returns the hash; the
 // sample 1-in-64 is (h & 63) == 0, 1-in-1024 (h & 1023) == 0.
 SOAP_DEV unsigned thin_hash(double x, double y, double z) {
-    unsigned long long h = (unsigned long long)__double_as_longlong(x) * 0x9E3779B97F4A7C15ull;
-    h ^= (unsigned long long)__double_as_longlong(y) * 0xC2B2AE3D27D4EB4Full;
-    h ^= (unsigned long long)__double_as_longlong(z) * 0x165667B19E3779F9ull;
-    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-    return (unsigned)h;
+    // (one integer multiply: the placement pass computes this for every particle, and 32-bit multiplies run at a quarter of the rate)
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y), bz = (unsigned long long)__double_as_longlong(z);
+    unsigned h = (unsigned)bx ^ (unsigned)(bx >> 32);
+    h ^= __builtin_rotateleft32((unsigned)by ^ (unsigned)(by >> 32), 11);
+    h ^= __builtin_rotateleft32((unsigned)bz ^ (unsigned)(bz >> 32), 22);
+    h ^= h >> 15; h *= 0x9E3779B1u; h ^= h >> 16;
+    return h;
 }
 
 // one payload record from global memory (field by field: the compiler merges them into 16-byte loads)

@@ -84,7 +84,10 @@ def engine_value(halo_result, group, key):
 
 # quantities that are sums of signed terms: compare with an absolute floor tied to the scale
 # of the terms ("fp64 parity at 1e-10 despite reduction order")
-def assert_close(name, got, want, rtol=1e-10, scale=0.0, atol_factor=1e-13):
+ATOL_FACTOR = 1e-12   # the one absolute floor of the engine-vs-oracle comparisons: 1e-12 x (scale of the summed terms)
+
+
+def assert_close(name, got, want, rtol=1e-10, scale=0.0, atol_factor=ATOL_FACTOR):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     tol = rtol * np.abs(want) + atol_factor * scale
