@@ -410,6 +410,7 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64b); SOAP_DECL_LAUNCH(soap_launch_halo_256b);
 SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s); SOAP_DECL_LAUNCH(soap_launch_halo_1024s);
 // the small-halo class (small_halo.hip): one wavefront per halo, slab in LDS; variants by slab entries and chunk content
 void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+int soap_small_global_128d();
 void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_1024d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_128i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
@@ -839,6 +840,7 @@ struct TypeHost {
 #define NSV 3   // variants of the small-halo kernels
 #define SMALL_MAXG512 (256 * 11)    // most persistent waves of the 512- / 1024-entry variants (slices of the streamed-column buffer)
 #define SMALL_MAXG1024 (256 * 8)
+#define SMALL_MAXG128 (256 * 24)
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
@@ -1896,20 +1898,22 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemsetAsync(h->d_small_esc, 0, sizeof(int), st));
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
-    if (!todo_small[1].empty() || !todo_small[2].empty()) {
+    if (!todo_small[1].empty() || !todo_small[2].empty() || (!todo_small[0].empty() && soap_small_global_128d())) {
         // the streamed columns of the 512- and 1024-entry variants: a slice per persistent wave, one region per variant
         // (sized for the largest grids launch_small may use, SMALL_MAXG512 / SMALL_MAXG1024 waves; the region of the 1024-entry
         // variant -- 117 MB -- only when that variant has work)
         const size_t need1 = (size_t)SMALL_MAXG512 * 7 * (size_t)small_ns[1] * sizeof(double);
         const size_t need2 = todo_small[2].empty() ? 0 : (size_t)SMALL_MAXG1024 * 7 * (size_t)small_ns[2] * sizeof(double);
-        if (h->small_cols_bytes < need1 + need2) {
+        const size_t need0 = (todo_small[0].empty() || !soap_small_global_128d()) ? 0 : (size_t)SMALL_MAXG128 * 7 * (size_t)small_ns[0] * sizeof(double);
+        if (h->small_cols_bytes < need1 + need2 + need0) {
             if (h->d_small_cols) (void)hipFree(h->d_small_cols);
             h->d_small_cols = nullptr;
-            HIPCHECK(hipMalloc((void **)&h->d_small_cols, need1 + need2));
-            h->small_cols_bytes = need1 + need2;
+            HIPCHECK(hipMalloc((void **)&h->d_small_cols, need1 + need2 + need0));
+            h->small_cols_bytes = need1 + need2 + need0;
         }
         P.small_cols = h->d_small_cols;
         P.small_cols2 = need2 ? (double *)((char *)h->d_small_cols + need1) : nullptr;
+        P.small_cols0 = need0 ? (double *)((char *)h->d_small_cols + need1 + need2) : nullptr;
         HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     TRACE("run: classified");
@@ -1922,7 +1926,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
     { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
     // every persistent wave of the 512- / 1024-entry variants owns a slice of the streamed-column buffer: never more waves than slices
-    groups_small[0] = std::max(1, groups_small[0]);
+    { const char *e = getenv("SOAP_ENGINE_GS128"); if (e) groups_small[0] = atoi(e); }
+    groups_small[0] = std::min(std::max(1, groups_small[0]), SMALL_MAXG128);
     groups_small[1] = std::min(std::max(1, groups_small[1]), SMALL_MAXG512);
     groups_small[2] = std::min(std::max(1, groups_small[2]), SMALL_MAXG1024);
     auto launch_small = [&](int v, std::vector<int> &list, hipEvent_t after, bool join) -> int32_t {

@@ -216,6 +216,7 @@ struct RunParams {
     int *small_esc;               // small-halo class: [0] number of rows in the list behind it -- halos that outgrew the class' slab are appended
                                   // and done by the wavefront class, launched behind the small-halo kernels with this list (null: status only)
     double *small_cols2;          // ... the streamed columns of the 1024-entry variant (the 512-entry one uses small_cols)
+    double *small_cols0;          // ... and of the 128-entry variant when it is built with its columns in global memory
 };
 
 // ------------------------------------------------------------------------------------------

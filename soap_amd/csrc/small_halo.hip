@@ -1320,7 +1320,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
         g_W.L = P.boxsize; g_W.nu_density = P.nu_density; g_W.a = P.a; g_W.mpc = P.mpc; g_W.mpc20 = P.mpc20; g_W.G_eff = P.G_eff;
         g_W.hydro = P.hydro; g_W.has_nu = P.has_nu;
 #if SGLOBAL
-        g_W.cols = (GAS double *)(SNS > 512 ? P.small_cols2 : P.small_cols) + (long long)blockIdx.x * (SC_NCOLS * SNS);
+        g_W.cols = (GAS double *)(SNS > 512 ? P.small_cols2 : (SNS > 128 ? P.small_cols : P.small_cols0)) + (long long)blockIdx.x * (SC_NCOLS * SNS);
 #endif
 #ifdef SMALL_CHECK
         g_W.dbg = (unsigned long long *)P.phase;
@@ -1729,3 +1729,5 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
 extern "C" void SOAP_CAT4(soap_launch_small_, SNS, SVAR, )(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo) {
     hipLaunchKernelGGL(SOAP_CAT4(k_small, SNS, SVAR, ), dim3(groups), dim3(64), 0, stream, params, queue, todo, n_todo);
 }
+// 1: this variant keeps its streamed columns in a per-wave slice of global memory (engine.hip provides RunParams.small_cols*)
+extern "C" int SOAP_CAT4(soap_small_global_, SNS, SVAR, )() { return SGLOBAL; }
