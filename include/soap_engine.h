@@ -172,12 +172,18 @@ int32_t soap_engine_destroy(soap_engine *h);
  *   grnr           [n]    GroupNr_bound, int32 or int64 (grnr_bytes = 4 or 8)
  *   fof            [n]    FOFGroupIDs int64
  *   resolution     mesh cells per dimension (chunk_tasks.py:299-302 computes it)
- *   on_device      0: host pointers, 1: device (HBM) pointers on cfg.device
+ *   on_device      0: host pointers, 1: device (HBM) pointers on cfg.device, 2: device pointers and an ASYNCHRONOUS call -- it
+ *                  returns once the mesh is known and the placement pass (the copy into cell order and payload records, most of
+ *                  the staging time) is queued on the engine's stream; the next call on the handle that needs the mesh
+ *                  (soap_engine_run, another soap_engine_stage_*, soap_engine_membership, the "mesh" / "reorder" clocks,
+ *                  soap_engine_destroy) completes it and reports its errors.  soap_engine_stage_halos does not wait for it: the
+ *                  host prepares the halo table while the device places the particles.
  * The call copies everything it needs: the coordinates into cell order (structure of arrays, what the candidate stream of
  * a halo reads) and velocity, mass, GroupNr_bound, FOF id, coordinates and original index of every particle into one
  * 80-byte payload record at the particle's cell-ordered position (what the slab build of a halo gathers).  Lifetime: every
- * input array, host or device, may be reused or freed as soon as the call returns; with on_device == 0 the device copies
- * made for the mesh build go back to the handle's allocation cache before it returns.
+ * input array, host or device, may be reused or freed as soon as the call returns (on_device == 2: as soon as the call that
+ * completes the staging returns; until then the arrays must stay allocated and unmodified); with on_device == 0 the device
+ * copies made for the mesh build go back to the handle's allocation cache before it returns.
  */
 int32_t soap_engine_stage_particles(soap_engine *h, int32_t type_slot, int64_t n,
                                     const double *pos, const void *vel, const void *mass, int32_t value_bytes,

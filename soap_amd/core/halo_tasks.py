@@ -206,10 +206,19 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
 
     ok = status == STATUS_OK
     again = status == STATUS_NEED_LARGER_READ_RADIUS
-    halo_arrays["done"][todo[ok]] = 1
     upd = again | ok   # finished halos carry the radii of their in-engine retries (resident_radius), if any
-    halo_arrays["read_radius"][todo[upd]] = out["read_radius"][upd]
-    halo_arrays["search_radius"][todo[upd]] = out["search_radius"][upd]
+    if todo.size == len(halo_arrays["done"]):
+        # first call for a chunk: rows of the engine ARE the rows of halo_arrays (masked copies instead of index gathers)
+        if ok.all():
+            halo_arrays["done"][:] = 1
+        else:
+            halo_arrays["done"][ok] = 1
+        np.copyto(halo_arrays["read_radius"], out["read_radius"], where=upd)
+        np.copyto(halo_arrays["search_radius"], out["search_radius"], where=upd)
+    else:
+        halo_arrays["done"][todo[ok]] = 1
+        halo_arrays["read_radius"][todo[upd]] = out["read_radius"][upd]
+        halo_arrays["search_radius"][todo[upd]] = out["search_radius"][upd]
     # --record-halo-timings columns (halo_centres.py:205-226): loops of the x1.2 radius search and attempts, summed
     # over every time the halo was processed (halo_tasks.py:188-191 for the attempt that finishes, :411-414 otherwise)
     if "n_loop" in halo_arrays:
@@ -230,6 +239,6 @@ def process_halos(engine: Engine, halo_prop_list: List, cellgrid, halo_arrays: D
                     halo_result[f"InputHalos/{name}"] = (np.asarray(halo_arrays[name][i]), desc, True, None)
             results.append(halo_result)
 
-    nr_left = int(np.sum(np.asarray(halo_arrays["done"]) == 0))
+    nr_left = len(halo_arrays["done"]) - int(np.count_nonzero(halo_arrays["done"]))
     raw = dict(out, rows=todo)
-    return time.time() - t0_all, task_time, nr_left, int(ok.sum()), raw
+    return time.time() - t0_all, task_time, nr_left, int(np.count_nonzero(ok)), raw

@@ -919,7 +919,12 @@ struct soap_engine {
     long long n_pipeline = 0, n_single = 0, n_small_escalated = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_in = nullptr;
+    // staging that returned with its last kernels still in flight (on_device = 2): completed -- synchronised, checked, timed, its
+    // temporaries released -- by the next call that needs the mesh (finish_stage)
+    bool stage_pending = false;
+    int stage_pending_slot = -1;
+    std::vector<std::pair<void *, size_t>> stage_scratch;
     // team run (k_team): its own stream (highest priority: launched first, resident from the start), control block, clocks
     hipStream_t team_stream = nullptr;
     hipEvent_t team_start = nullptr, team_done = nullptr;
@@ -1034,6 +1039,7 @@ static int32_t create_resources(soap_engine *h) {
     HIPCHECK(hipStreamCreate(&h->stream));
     HIPCHECK(hipEventCreate(&h->ev0));
     HIPCHECK(hipEventCreate(&h->ev1));
+    HIPCHECK(hipEventCreate(&h->ev2));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIPCHECK(hipMalloc((void **)&h->d_queue, sizeof(unsigned)));
     // one stream per thread-group class, on distinct priority levels where the device offers three:
@@ -1095,9 +1101,30 @@ static void free_halos(soap_engine *h) {
     h->n_halo = 0;
 }
 
+// completes a staging call that returned early (on_device = 2): what stage_type does at its end otherwise
+static int32_t finish_stage(soap_engine *h) {
+    if (!h->stage_pending) return 0;
+    h->stage_pending = false;
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    const hipError_t le = hipGetLastError();
+    for (auto &p : h->stage_scratch) h->pool.release(p.first, p.second);
+    h->stage_scratch.clear();
+    if (se != hipSuccess || le != hipSuccess) {
+        if (h->stage_pending_slot >= 0) h->t[h->stage_pending_slot].release(h->pool);   // never a half-built mesh
+        return fail(-101, std::string("mesh build: ") + hipGetErrorString(se != hipSuccess ? se : le));
+    }
+    float ms1 = 0, ms2 = 0;
+    (void)hipEventElapsedTime(&ms1, h->ev0, h->ev1);
+    (void)hipEventElapsedTime(&ms2, h->ev1, h->ev2);
+    h->ms_mesh = ms1;
+    h->ms_reorder = ms2;
+    return 0;
+}
+
 int32_t soap_engine_destroy(soap_engine *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
+    (void)finish_stage(h);
     const bool trace = getenv("SOAP_ENGINE_TRACE") != nullptr;
     auto probe = [&](const char *tag) { const hipError_t e = hipGetLastError(); if (e != hipSuccess && trace) { fprintf(stderr, "[soap_engine] destroy: %s left %s\n", tag, hipGetErrorString(e)); fflush(stderr); } };
     probe("before");
@@ -1153,6 +1180,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     probe("tables");
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     probe("events");
@@ -1222,6 +1250,7 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     if (value_bytes != 4 && value_bytes != 8) return fail(-4, "value_bytes (Velocities / Masses / Weights) must be 4 or 8");
     if (resolution < 1 || resolution > 256) return fail(-5, "mesh resolution must be in [1,256]");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    { const int32_t frc = finish_stage(h); if (frc) return frc; }
     (void)hipGetLastError();   // (a stale error of an earlier, unrelated call is not this call's failure)
     DevPool &pool = h->pool;
     h->t[ts].release(pool);
@@ -1234,7 +1263,8 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
     TypeHost T;
     std::vector<std::pair<void *, size_t>> inputs;    // device copies of host inputs
     std::vector<std::pair<void *, size_t>> scratch;   // temporaries of the mesh build
-    hipEvent_t ev2 = nullptr;
+    const hipEvent_t ev2 = h->ev2;
+    bool deferred = false;
     auto grab = [&](void **p, size_t bytes, std::vector<std::pair<void *, size_t>> &owner) -> hipError_t {
         hipError_t e = pool.alloc(p, bytes);
         if (e == hipSuccess) owner.push_back({*p, bytes});
@@ -1340,7 +1370,6 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
             t_vbytes = 8;
             t_g32 = nullptr; t_g64 = nullptr; t_fof = nullptr;
         }
-        HIPCHECK(hipEventCreate(&ev2));
         HIPCHECK(pool.alloc((void **)&T.pay, (size_t)n * sizeof(Pay)));
         ThinBuild thin;
         memset(&thin, 0, sizeof(thin));
@@ -1387,6 +1416,14 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
             }
         }
         HIPCHECK(hipEventRecord(ev2, st));
+        if (on_device == 2) {
+            // the caller keeps the inputs alive and unmodified until the next call on this handle that needs the mesh: the placement
+            // pass stays in flight, finish_stage() completes the call
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(-101, std::string("mesh build: ") + hipGetErrorString(le));
+            deferred = true;
+            return 0;
+        }
         HIPCHECK(hipStreamSynchronize(st));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(-101, std::string("mesh build: ") + hipGetErrorString(le));
@@ -1398,7 +1435,13 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         return 0;
     };
     const int32_t rc = body();
-    if (ev2) (void)hipEventDestroy(ev2);
+    if (deferred && rc == 0) {
+        h->stage_scratch = scratch;
+        h->stage_pending = true;
+        h->stage_pending_slot = ts;
+        h->t[ts] = T;
+        return 0;
+    }
     for (auto &p : scratch) pool.release(p.first, p.second);
     if (rc != 0) {
         (void)hipStreamSynchronize(st);   // nothing may still be writing into what goes back to the cache
@@ -1438,7 +1481,9 @@ int32_t soap_engine_stage_halos(soap_engine *h, int64_t n, const double *cofp,
     HIPCHECK(h->pool.alloc((void **)&h->d_central, (size_t)n * 4));
     HIPCHECK(h->pool.alloc((void **)&h->d_status, (size_t)n * 4));
     HIPCHECK(h->pool.alloc((void **)&h->d_todo, (size_t)n * 4));
-    hipStream_t st = h->stream;
+    // (not behind a placement pass that may still be in flight on the engine's main stream: the teams' stream is idle between runs.
+    // No stream of its own -- one more stream changes which hardware queues the class streams share, and with that the halo phase)
+    hipStream_t st = h->team_stream;
     HIPCHECK(hipMemcpyAsync(h->d_cofp, cofp, (size_t)n * 24, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(h->d_search, search_radius, (size_t)n * 8, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(h->d_read, read_radius, (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -1459,8 +1504,8 @@ int32_t soap_engine_set_resident_radius(soap_engine *h, const double *resident_r
     if (h->d_resident) { h->pool.release(h->d_resident, n * 8); h->d_resident = nullptr; }
     if (!resident_radius || n == 0) return 0;
     HIPCHECK(h->pool.alloc((void **)&h->d_resident, n * 8));
-    HIPCHECK(hipMemcpyAsync(h->d_resident, resident_radius, n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpyAsync(h->d_resident, resident_radius, n * 8, hipMemcpyHostToDevice, h->team_stream));
+    HIPCHECK(hipStreamSynchronize(h->team_stream));
     return 0;
 }
 
@@ -1513,6 +1558,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (calcs[0].kind != SOAP_CALC_SUBHALO)
         return fail(-4, "the first calculation must be the bound subhalo (compute_halo_properties.py:232-247)");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    { const int32_t frc = finish_stage(h); if (frc) return frc; }   // (a staging call that returned with its placement pass in flight)
     std::vector<int> coloff(n_calcs);
     long long ncols = 0;
     bool want_inertia = false, want_property_radius = false;
@@ -2740,6 +2786,7 @@ int64_t soap_engine_membership(soap_engine *h, int64_t row, int32_t ts, double r
     if (row < 0 || row >= h->n_halo) return fail(-2, "row out of range");
     if (ts < 0 || ts >= SOAP_NTYPES) return fail(-3, "type_slot out of range");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    { const int32_t frc = finish_stage(h); if (frc) return frc; }
     const TypeHost &T = h->t[ts];
     if (T.n == 0) return 0;
     double c[3];
@@ -2813,8 +2860,10 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_team_failed")) return (double)h->n_team_failed;
     if (!strcmp(name, "halo_team")) return h->ms_team;
     if (!strcmp(name, "n_passes")) return (double)h->n_passes;   // launches of the single-kernel path (more than one: slab overflows)
-    if (!strcmp(name, "mesh")) return h->ms_mesh;
-    if (!strcmp(name, "reorder")) return h->ms_reorder;
+    if (!strcmp(name, "mesh") || !strcmp(name, "reorder")) {
+        (void)finish_stage(const_cast<soap_engine *>(h));   // (the events of a staging call still in flight)
+        return !strcmp(name, "mesh") ? h->ms_mesh : h->ms_reorder;
+    }
     return -1.0;
 }
 

@@ -7,6 +7,7 @@ residency, it never computes anything on this path).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Sequence
 
 import numpy as np
@@ -111,6 +112,7 @@ class Engine:
         cfg.hubble = float(hubble)
         cfg.rdot_omega = float(rdot_omega)
         self._h = C.c_void_p()
+        self._in_flight = None   # arrays of a staging call whose placement pass is still running on the device
         self._check(self._lib.soap_engine_create(C.byref(cfg), C.byref(self._h)))
         self.n_halo = 0
         self.calcs = []
@@ -131,7 +133,10 @@ class Engine:
             pass
 
     # -- staging ---------------------------------------------------------------------
-    def stage_particles(self, type_slot, pos, vel, mass, grnr, fof, resolution=None):
+    def stage_particles(self, type_slot, pos, vel, mass, grnr, fof, resolution=None, asynchronous=True):
+        """`asynchronous` (device arrays only): return with the placement pass still in flight (on_device = 2 of
+        soap_engine_stage_particles); the engine keeps references to the arrays until the next `run` has completed the call, the
+        caller must not write into them before that."""
         n = int(pos.shape[0])
         if resolution is None:
             resolution = mesh_resolution(n)
@@ -154,13 +159,17 @@ class Engine:
             raise ValueError("Coordinates/Velocities must have shape (n, 3)")
         if dev:
             self._order_after_torch(pos)
+        mode = (2 if asynchronous and n > 0 and os.environ.get("SOAP_ENGINE_ASYNC_STAGE", "1") != "0" else 1) if dev else 0
         self._check(
             self._lib.soap_engine_stage_particles(
                 self._h, int(type_slot), n, p_pos, p_vel, p_m, 4 if vdt == np.float32 else 8, p_g, gb, p_f,
-                int(resolution), 1 if dev else 0,
+                int(resolution), mode,
             )  # fmt: skip
         )
-        # (the call has consumed every array: include/soap_engine.h, lifetime rule)
+        if mode == 2:
+            # still being read on the engine's stream: the arrays (and their widened / contiguous copies) live until the next
+            # call that completes the staging (include/soap_engine.h, lifetime rule)
+            self._in_flight = [pos, vel, mass, grnr, fof, k1, k2, k3, k4, k5]
         del k1, k2, k3, k4, k5
 
     def _order_after_torch(self, tensor):
@@ -245,7 +254,10 @@ class Engine:
                 "split the list into several runs, each starting with the bound subhalo (INTEGRATION.md)")
         arr = (CalcDesc * len(calcs))(*calcs)
         td = -1.0 if target_density is None else float(target_density)
-        self._check(self._lib.soap_engine_run(self._h, arr, len(calcs), td))
+        try:
+            self._check(self._lib.soap_engine_run(self._h, arr, len(calcs), td))
+        finally:
+            self._in_flight = None   # (the run has completed a staging call that was still in flight)
         self.calcs = list(calcs)
 
     def desc_columns(self, desc) -> int:
