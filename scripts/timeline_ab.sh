@@ -14,7 +14,10 @@ for f in glob.glob(f'gpurun_out/tl_{tag}/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '')[:60], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', ''), r.get('LDS_Block_Size', '')))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith('k_estimate') or r[2].startswith('k_predict')]
+# a run starts with k_estimate (+ k_predict); the giants' pipeline calls k_estimate again inside a run (with a rebuild radius): the
+# last k_predict marks the last run where there is one
+pred = [i for i, r in enumerate(rows) if r[2].startswith('k_predict')]
+starts = pred if pred else [i for i, r in enumerate(rows) if r[2].startswith('k_estimate')]
 i0 = starts[-1]
 while i0 > 0 and (rows[i0 - 1][2].startswith('k_predict') or rows[i0 - 1][2].startswith('k_estimate')):
     i0 -= 1

@@ -594,7 +594,7 @@ __device__ __forceinline__ long long pred_candidates(const RunParams &P, long lo
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
     return tot;
 }
-__global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_first, long long *est, int min_samples, double margin, int force) {
+__global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_first, long long *est, int min_samples, double margin, int force, long long always_above) {
     __shared__ int s_ibin[BLK / 64][PRED_K];
     __shared__ double s_dens[BLK / 64][PRED_K];
     const RunParams &P = *Pp;
@@ -608,15 +608,24 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
     const double R0 = fmin(Rread, Rs * P.first_factor);
     double out = 0.0;
     // Only a halo whose first sphere holds many times its own bound particles can be inside another's envelope: everybody else
-    // keeps the estimate k_estimate left (this kernel needs three times its registers: it runs for the suspects only)
+    // keeps the estimate k_estimate left (this kernel needs three times its registers: it runs for the suspects only) -- and every
+    // halo of the thread-group classes (more than `always_above` candidates): there a first sphere that turns out too small is a chain of
+    // rebuilds on ONE workgroup, the longest thing in the pass (uncapped C3 box: one central of 1.1e5 candidates whose loop ends beyond
+    // 5e5 entries kept the 256-thread class busy for 23 ms and was then done again in a pass of its own)
     const long long cand0 = est[h];
-    const bool suspect = force || cand0 > 8ll * (long long)P.halo.nr_bound[h] + 2048ll;
+    const bool suspect = force || cand0 > 8ll * (long long)P.halo.nr_bound[h] + 2048ll || cand0 > always_above;
     const bool central = P.halo.is_central[h] == 1 && P.target_density > 0.0;
     if (!suspect || !central) { if (lane == 0) r_first[h] = 0.0; return; }
     if (cap > R0 * 1.0001) {
         const double cx = P.halo.cofp[3 * h], cy = P.halo.cofp[3 * h + 1], cz = P.halo.cofp[3 * h + 2], L = P.boxsize;
         const double inv_log = 1.0 / log2(1.2);
         double binv = 0.0;    // lane k: mass of the thinned particles (times the thinning factor) on ladder step k, all types
+        double bcnt = 0.0;    // ... and how many thinned particles that is
+        // the halo's own bound particles lie inside the catalogue's search radius, i.e. inside every ladder step, whether the thinning
+        // kept any of them or not (a central of 40 particles has none in a 1-in-64 sample: its ladder would start at zero density)
+        double own_mass = 0.0;
+        for (int ts = 0; ts < SOAP_NTYPES; ts++) if (P.t[ts].n > 0) own_mass = fmax(own_mass, P.t[ts].mean_mass);
+        own_mass *= (double)P.halo.nr_bound[h];
         double Rlo = -1.0, Rhi = R0, need = 0.0;
         int nsamp = 0;
         for (int iter = 0; iter < 8; iter++) {
@@ -684,13 +693,19 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 // (integer counts per type, added in type order: the same sum whatever order the particles came in)
                 binv += (double)ibin[lane] * (T.mean_mass * (coarse ? 1024.0 : 64.0));
+                bcnt += (double)ibin[lane];
             }
             (void)cand;
             // ---- the loop on the ladder: lane k holds step k
             const double Rk = Rs * exp2((double)lane * log2(1.2));
-            double M = binv;
-            for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(M, o, 64); if (lane >= o) M += v; }
+            double M = binv, C = bcnt;
+            for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(M, o, 64), w = __shfl_up(C, o, 64); if (lane >= o) { M += v; C += w; } }
             const bool known = Rk <= Rhi * 1.000001;      // steps the thinned sphere covers
+            // The enclosed mass of a step is known to about two standard deviations of its sample count; the ladder takes the UPPER end
+            // and adds the halo's own particles (a density that is too high ends the guessed loop later: a larger first sphere than
+            // needed costs a little, a smaller one a rebuild -- a handful of samples at the inner steps used to read as "every threshold
+            // crossed at the first step", and 5 x R500 of such a crossing as the end of the loop)
+            M = own_mass + M * (1.0 + 2.0 / sqrt(fmax(C, 1.0)));
             dens[lane] = known ? M / (4.0 / 3.0 * M_PI * Rk * Rk * Rk) : 1e300;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (iter == 0) {
@@ -1709,7 +1724,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         hipLaunchKernelGGL(k_estimate, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, d_est, (const double *)nullptr);
         if (pred) {
             const int pred_force = getenv("SOAP_ENGINE_PRED_FORCE") && atoi(getenv("SOAP_ENGINE_PRED_FORCE")) != 0;
-            hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_min, pred_margin, pred_force);
+            long long pred_always = nb_small;
+            { const char *e = getenv("SOAP_ENGINE_PRED_ALWAYS"); if (e) pred_always = atoll(e); }
+            hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_min, pred_margin, pred_force, pred_always);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(h->h_first.data(), h->d_first, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));   // (first_radius set)
@@ -1718,6 +1735,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipStreamSynchronize(st));
         h->pool.release(d_est, (size_t)h->n_halo * 8);
         for (double v : h->h_first) h->n_predicted += v > 0.0;
+        if (const char *dump = getenv("SOAP_ENGINE_DUMP_EST")) {   // diagnostic: the estimates and the guessed radii of this run, raw (int64[n], float64[n])
+            if (FILE *f = fopen(dump, "wb")) { fwrite(est.data(), 8, (size_t)h->n_halo, f); fwrite(h->h_first.data(), 8, (size_t)h->n_halo, f); fclose(f); }
+        }
     }
     TRACE("run: estimate done");
     // ---- class limits follow the load.  A halo is a serial chain on ONE thread group: ~4e-7 s per candidate on a
