@@ -19,7 +19,7 @@ cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl, inertia=os.envi
 hn = {k: v.cpu().numpy() for k, v in halos.items()}
 H = len(hn["index"])
 ref = None
-names = ("halo", "halo_small", "halo_small512", "halo_small1024", "halo_wave", "halo_wg256", "halo_wg1024", "halo_team", "pipe_build", "pipe_stage_a", "pipe_stage_b", "run_classify", "run_total")
+names = ("reorder", "halo", "halo_small", "halo_small512", "halo_small1024", "halo_wave", "halo_wg256", "halo_wg1024", "halo_team", "pipe_build", "pipe_stage_a", "pipe_stage_b", "run_classify", "run_total")
 counts = ("n_small128", "n_small512", "n_small1024", "n_small_escalated", "n_wave", "n_wg256", "n_wg1024", "n_pipeline", "n_passes", "n_predicted", "n_team", "n_team_failed")
 for cfg in sys.argv[1:] or ["-"]:
     sets = [kv.split("=", 1) for kv in cfg.split(",") if "=" in kv]
