@@ -403,6 +403,7 @@ __global__ void k_scatter_pos(const unsigned *cell, const unsigned *rank, long l
 extern "C" {
 #define SOAP_DECL_LAUNCH(name) void name(int groups, hipStream_t stream, const RunParams *params, SlabDev slab, unsigned *queue, const int *todo, long long n_todo)
 SOAP_DECL_LAUNCH(soap_launch_halo_64n); SOAP_DECL_LAUNCH(soap_launch_halo_64i);
+SOAP_DECL_LAUNCH(soap_launch_halo_64n32); SOAP_DECL_LAUNCH(soap_launch_halo_64i32);   // LDS tables for 32 calculations: eight groups per CU
 SOAP_DECL_LAUNCH(soap_launch_halo_256n); SOAP_DECL_LAUNCH(soap_launch_halo_256i);
 SOAP_DECL_LAUNCH(soap_launch_halo_1024n); SOAP_DECL_LAUNCH(soap_launch_halo_1024i);
 // pipeline stages (GMODE 1: build, GMODE 2: property passes) and the radius loop with lanes = halos (stage_a.hip)
@@ -1764,6 +1765,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // counts that disagree with the catalogue, a loop that runs past the first superset -- fall through to the
     // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
     // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
+    // the wavefront class' unit with LDS tables for 32 calculations (eight groups per CU instead of seven) for the lists that fit
+    const bool narrow64 = n_calcs <= 32 && !(getenv("SOAP_ENGINE_NARROW64") && atoi(getenv("SOAP_ENGINE_NARROW64")) == 0);
     auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
         // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
         // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
@@ -1790,11 +1793,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(C.start, cs));
             C.nh += nt;
             if (!want_inertia) {
-                if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                if (k == 0 && narrow64) soap_launch_halo_64n32(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
                 else if (k == 1) soap_launch_halo_256n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
                 else soap_launch_halo_1024n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
             } else {
-                if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                if (k == 0 && narrow64) soap_launch_halo_64i32(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
+                else if (k == 0) soap_launch_halo_64i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
                 else if (k == 1) soap_launch_halo_256i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
                 else soap_launch_halo_1024i(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
             }
@@ -2075,8 +2080,8 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
         const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size() + todo_small[2].size()));
         if (C.nh == 0) HIPCHECK(hipEventRecord(C.start, cs));   // (no launch of the class' own in this run: its clock starts here)
-        if (!want_inertia) soap_launch_halo_64n(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
-        else soap_launch_halo_64i(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+        if (!want_inertia) (narrow64 ? soap_launch_halo_64n32 : soap_launch_halo_64n)(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
+        else (narrow64 ? soap_launch_halo_64i32 : soap_launch_halo_64i)(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;

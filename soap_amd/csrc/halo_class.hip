@@ -62,9 +62,13 @@
 #define SOAP_VARIANT b      // pipeline stage 1: build the sorted superset in the arena
 #elif GMODE == 2
 #define SOAP_VARIANT s      // pipeline stage 3: the property passes
+#elif GINERTIA && defined(LCALC)
+#define SOAP_VARIANT i32    // ... with LDS tables for LCALC (32) calculations instead of MAXCALC: one more resident group per CU
 #elif GINERTIA
 #define SOAP_VARIANT i      // the single-kernel path with the inertia tensor passes compiled in (their registers and
-#else                       // stack stay out of the variant every other run uses)
+#elif defined(LCALC)        // stack stay out of the variant every other run uses)
+#define SOAP_VARIANT n32
+#else
 #define SOAP_VARIANT n
 #endif
 
