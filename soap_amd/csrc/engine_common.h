@@ -387,7 +387,9 @@ SOAP_DEV double wave_scan_max(double v) {
 // per-halo kernel
 // ------------------------------------------------------------------------------------------
 #define NACC 76
+#ifndef PREFB
 #define PREFB 12        // calculations whose prefix moments are finalised together
+#endif
 #define NHM 5           // half-mass weight classes: all, dark matter, gas, stars, baryons
 enum {
     A_N0 = 0, A_N1, A_N2, A_N3,        // counts per type slot

@@ -10,11 +10,18 @@
 #define GRP 64
 #define GNW 1
 #define GWG 64
+#ifdef G64_CH
+#define GCH G64_CH         // (experiments: scripts/build_variant.sh)
+#else
 #define GCH 1024
+#endif
 #define SORT_NBMAX 64
 #define GLB 4
 #define SCAN_E 2           // consecutive particles per lane in the radial scan (fused_scan): most halos of this class fit one or two blocks anyway (4: 13.9 ms for the class alone on C3, 2: 13.6, 1: 13.6)
-#define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
+#ifndef G64_WPE
+#define G64_WPE 2
+#endif
+#define GATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G64_WPE, 8)))   // at most 256 registers (VGPR + AGPR): two wavefronts per SIMD
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #elif GCLASS == 256
 #define GRP 256
