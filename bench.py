@@ -63,9 +63,10 @@ WORKLOADS = {
                name="synthetic DMO 1e7 particles / 1e4 halos, BoundSubhalo + SO_200_crit; "
                     "inertia tensors off; halo sizes capped at 3e5 particles"),
     "c5": dict(n_part=25_000_000, n_halo=25_000, so="default", apertures=(30.0, 50.0, 100.0),
-               projected=(10.0, 30.0, 50.0, 100.0), hydro=True,
+               projected=(10.0, 30.0, 50.0, 100.0), hydro=True, float32_masses=True,
                name="synthetic hydro (gas+DM+stars+BH) 2.5e7 particles / 2.5e4 halos (the per-GPU share of 2e8 on 8 "
-                    "GPUs), BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc + projected 10/30/50/100 kpc; inertia tensors off"),
+                    "GPUs), masses float32-valued as SWIFT stores them, BoundSubhalo + 9 SO + incl/excl 30/50/100 kpc + "
+                    "projected 10/30/50/100 kpc; inertia tensors off"),
     "giant": dict(n_part=20_000_000, n_halo=2_000, so="default", apertures=(30.0, 50.0, 100.0), max_halo=1_000_000,
                   name="synthetic DMO 2e7 particles / 2e3 halos with the halo size cap lifted to 1e6 particles, "
                        "C3 calculation list; inertia tensors off"),
@@ -306,7 +307,7 @@ def main():
     t_gen = time.time()
     # every rank builds the SAME box (same seed) and keeps its chunk's region of it
     sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=args.seed, device=dev, hydro=wl.get("hydro", False),
-                                 max_halo=wl.get("max_halo"), topcells=TOPCELLS)
+                                 max_halo=wl.get("max_halo"), topcells=TOPCELLS, float32_masses=wl.get("float32_masses", False))
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     cf, so_vars, ap_vars, pj_vars, props = build_props(sc, wl)

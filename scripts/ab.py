@@ -14,7 +14,7 @@ seed = int(os.environ.get("SEED", "1234"))
 reps = int(os.environ.get("REPS", "3"))
 check = os.environ.get("CHECK") == "1"
 wl = bench.WORKLOADS[key]
-sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=seed, device="cuda:0", hydro=wl.get("hydro", False), max_halo=wl.get("max_halo"), topcells=bench.TOPCELLS)
+sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=seed, device="cuda:0", hydro=wl.get("hydro", False), max_halo=wl.get("max_halo"), topcells=bench.TOPCELLS, float32_masses=os.environ.get("F32_MASSES") == "1" or wl.get("float32_masses", False))
 cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl, inertia=os.environ.get("BENCH_INERTIA") == "1")
 hn = {k: v.cpu().numpy() for k, v in halos.items()}
 H = len(hn["index"])

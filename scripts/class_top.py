@@ -11,7 +11,7 @@ from soap_amd.synthetic import make_chunk
 k = sys.argv[1] if len(sys.argv) > 1 else "1"
 key = os.environ.get("WL", "c3")
 wl = bench.WORKLOADS[key]
-sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=int(os.environ.get("SEED", "1234")), device="cuda:0", hydro=wl.get("hydro", False), max_halo=wl.get("max_halo"), topcells=bench.TOPCELLS)
+sc, data, halos = make_chunk(wl["n_part"], wl["n_halo"], seed=int(os.environ.get("SEED", "1234")), device="cuda:0", hydro=wl.get("hydro", False), max_halo=wl.get("max_halo"), topcells=bench.TOPCELLS, float32_masses=os.environ.get("F32_MASSES") == "1" or wl.get("float32_masses", False))
 cf, so_vars, ap_vars, pj_vars, props = bench.build_props(sc, wl)
 hn = {kk: v.cpu().numpy() for kk, v in halos.items()}
 H = len(hn["index"])

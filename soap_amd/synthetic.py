@@ -71,6 +71,7 @@ def make_chunk(
     nmin: int = 50,
     topcells: int = 16,
     max_halo: int | None = None,
+    float32_masses: bool = False,
 ):
     """
     Returns (scalars, data, halos):
@@ -186,6 +187,9 @@ def make_chunk(
     if hydro:
         # unequal masses per type exercise the weighted paths
         mass = mass * (0.5 + rand(n_part))
+        if float32_masses:
+            # the values a SWIFT snapshot holds (its Masses datasets are float32), kept in float64 arrays
+            mass = mass.to(torch.float32).to(torch.float64)
 
     # ---- SWIFT-like storage order: by coarse top-level cell, random inside -----------------
     tc = torch.clamp((pos / (L / topcells)).floor().to(torch.int64), 0, topcells - 1)

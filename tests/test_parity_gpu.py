@@ -250,8 +250,8 @@ def test_projected_apertures_match_oracle(built_library):
     engine.close()
 
 
-@pytest.mark.parametrize("engine_kw", [{}, {"slab_capacity": 256, "n_workgroups": 8}],
-                         ids=["default-classes", "small-slab-forces-256-and-1024-thread-groups"])
+@pytest.mark.parametrize("engine_kw", [{}, {"slab_capacity": 256, "n_workgroups": 8}, {"slab_capacity": 256, "n_workgroups": 8, "f32_valued": True}],
+                         ids=["default-classes", "small-slab-forces-256-and-1024-thread-groups", "float32-valued-masses-exact-running-sums"])
 def test_hydro_chunk_matches_oracle(built_library, engine_kw):
     """Four particle types (gas, DM, stars, BHs) with unequal masses: type-major concatenation of
     the reference (SO_properties.py:3520-3550) only shows up as summation order; counts and masses
@@ -262,6 +262,14 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
     build) instead of the wavefront class."""
     sc, data, halos = make_chunk(160000, 100, seed=33, hydro=True)
     data_np, halos_np = to_numpy(data, halos)
+    engine_kw = dict(engine_kw)
+    f32_valued = engine_kw.pop("f32_valued", False)
+    if f32_valued:
+        # Masses as SWIFT snapshots hold them: float32 values (here in float64 arrays).  Every partial sum of the cumulative mass is
+        # then exact in fp64, and the thread-group classes sum the chunks of the slab build in parallel instead of along one chain --
+        # the same numbers as numpy.cumsum to the bit, or the SO radii and memberships below would not agree
+        for d in data_np.values():
+            d["Masses"] = d["Masses"].astype(np.float32).astype(np.float64)
     cf = CategoryFilter(dmo=False)
     so_vars = {"200_crit": {"value": 200.0, "type": "crit"}, "500_crit": {"value": 500.0, "type": "crit"},
                "BN98": {"value": 0.0, "type": "BN98"}}  # fmt: skip
@@ -273,6 +281,7 @@ def test_hydro_chunk_matches_oracle(built_library, engine_kw):
     assert np.array_equal(ha["done"], ha_ref["done"])
     if engine_kw:
         assert engine.kernel_ms("n_wg256") + engine.kernel_ms("n_wg1024") > 0
+        assert (engine.phase_cycles()["exact_cumsum_chunks"] > 0) == f32_valued
     nchecked = 0
     for j, row in enumerate(np.flatnonzero(ha["done"] == 1)):
         o, hr = ref[row], results[j]
