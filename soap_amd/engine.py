@@ -32,7 +32,7 @@ SLOT_OF_PTYPE = {0: 0, 1: 1, 4: 2, 5: 3}
 PHASE_NAMES = ("select", "sort", "materialize", "reduce", "scan", "so_search", "total", "misc",
                "reduce_xlane", "finalize_moments", "finalize_scan", "scan_argmax", "mat_cumsum", "so_thread0",
                "family_order", "stage_a", "prologue", "epilogue", "subhalo_spin", "projected",
-               "stage_b", "scan_setup", "sort_histogram", "sort_scatter", "sort_blocks", "flow_inner", "flow_shells") + ("",) * 4 + ("exact_cumsum_chunks",)  # fmt: skip
+               "stage_b", "scan_setup", "sort_histogram", "sort_scatter", "sort_blocks", "flow_inner", "flow_shells", "rotation") + ("",) * 3 + ("exact_cumsum_chunks",)  # fmt: skip
 # (the last slot is a count, not clocks: chunks of the slab build whose cumulative mass was summed in parallel because every partial sum is exact)
 
 
