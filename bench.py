@@ -146,6 +146,28 @@ def _cpu_worker(wid, payload_path, counter, budget_s, out):
     out[wid] = (evals, nh, time.perf_counter() - t0)
 
 
+def _cgroup_cpu_quota():
+    """CPU quota of this process' cgroup in cores (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), or None when there is
+    none: the affinity mask of a container usually shows the whole host, the quota is what the scheduler really grants."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return max(1, int(round(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0 and per > 0:
+            return max(1, int(round(q / per)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -241,9 +263,10 @@ def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
 
     try:
         v1, h1, n1, t1 = run(1, budget_s * 0.5)
-        # one worker per core of this process' share of the host: a one-GPU box of the pool gets 16 cores of a 256-thread
-        # host (the affinity mask does not say so); BENCH_CPU_CORES overrides
-        ncore = max(1, min(share, int(os.environ.get("BENCH_CPU_CORES", "16"))))
+        # one worker per core of this process' share of the host: the cgroup's CPU quota when there is one (a one-GPU box of the
+        # pool gets 16 cores of a 256-thread host, and its affinity mask does not say so), else 16; BENCH_CPU_CORES overrides
+        quota = _cgroup_cpu_quota()
+        ncore = max(1, min(share, int(os.environ.get("BENCH_CPU_CORES", str(quota if quota else 16)))))
         vN, hN, nN, tN = run(ncore, budget_s) if ncore > 1 else (v1, h1, n1, t1)
     finally:
         import shutil
@@ -252,7 +275,7 @@ def cpu_baseline(sc, data, halos, wl, budget_s=12.0):
     return {
         "value": vN, "unit": "evals/s", "cores": ncore, "kind": "port", "halos_per_s": hN,
         "one_core": {"value": v1, "halos_per_s": h1},
-        "host": {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "cpu_share_of_this_process": share},
+        "host": {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "cpu_share_of_this_process": share, "cgroup_cpu_quota": quota},
         "sample": f"{len(h_np['index'])} halos of the same box inside a {frac:.3f}L sub-cube ({npart} particles), biggest "
                   f"first off a shared counter, lap after lap until the time budget is spent: {nN} halos in {tN:.1f} s on "
                   f"{ncore} worker processes ({n1} in {t1:.1f} s on one); NumPy oracle, the true reference adds unyt overhead",
@@ -584,6 +607,20 @@ def main():
                 line["full_set"] = full
             except Exception as e:   # never hide the headline number
                 line["full_set"] = {"error": repr(e)}
+            # the other one-GPU configurations of BASELINE.json under the same clock, each with its own roofline block: configs[1]
+            # (c2: 1e7 / 1e4, BoundSubhalo + SO_200_crit) and the per-GPU share of configs[4] (c5: hydro, projected apertures)
+            other = {"note": "same process and measurement as full_set (1 untimed set-up pass + 1 step of passes_per_step passes), boxes of "
+                             "their own: `python bench.py --workload c2|c5` gives the same numbers as a headline line"}
+            for key in ("c2", "c5"):
+                try:
+                    wl_o = WORKLOADS[key]
+                    sc_o, data_o, halos_o = make_chunk(wl_o["n_part"], wl_o["n_halo"], seed=args.seed, device=dev, hydro=wl_o.get("hydro", False),
+                                                       max_halo=wl_o.get("max_halo"), topcells=TOPCELLS, float32_masses=wl_o.get("float32_masses", False))
+                    other[key] = variant_block(wl_o["name"], wl_o, sc_o, data_o, halos_o, False)
+                    del data_o, halos_o
+                except Exception as e:
+                    other[key] = {"error": repr(e)}
+            line["other_configs"] = other
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(sc, data, halos, wl)

@@ -1376,6 +1376,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
         cs.state = 0; cs.n = 0; cs.ev = -1; cs.R = 0.0; cs.M = 0.0;
         double counts[4] = {0.0, 0.0, 0.0, 0.0};
         double encl = 0.0;
+        int last_bound = -1;   // last slab entry bound to the halo: the passes over the bound members end there
         unsigned long long done = 0ull;
         double Rcur = Rsearch;
         int status = SOAP_HALO_OK;
@@ -1453,6 +1454,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                     else {
                         for (int k = 0; k < 4; k++) counts[k] = tot[k];
                         encl = uni(last >= 0 ? g_W.r[last] : 0.0);
+                        last_bound = last;
                         if (LANE == 0) { cs.state = 1; cs.n = n; cs.R = 0.0; cs.M = 0.0; }
                         done |= 1ull;
                     }
@@ -1603,7 +1605,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                     n_restart++;
                     for (int k = 0; k < 4; k++) counts[k] = 0.0;
                     cs.state = 0; cs.ev = -1;
-                    encl = 0.0;
+                    encl = 0.0; last_bound = -1;
                     done = 0ull;
                     Rcur = Rsearch;
                     n_loop = 0;
@@ -1618,7 +1620,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
         }
         if (status == SOAP_HALO_OK && dbg_stop != 1 && dbg_stop != 2 && dbg_stop != 3) {
             // ---- stage B: every property of every calculation in a few fused passes over the sorted slab
-            if (LANE == 0 && cs.state == 1) cs.n = nsel_final;   // all bound particles lie inside any later sphere
+            if (LANE == 0 && cs.state == 1) cs.n = last_bound + 1 < nsel_final ? last_bound + 1 : nsel_final;   // all bound particles lie inside any later sphere; the passes over them end at the last one
             const int kind = cd.kind;
             const bool isb = kind == SOAP_CALC_SUBHALO || kind == SOAP_CALC_APERTURE_EXCL;
             const bool fam = LANE < ncalc && cs.state == 1 && kind != SOAP_CALC_PROJECTED;
