@@ -716,7 +716,7 @@ def angular_momentum_and_kappa_corot(mass, position, velocity, ref_velocity, do_
     return Ltot, kappa_corot, M_counterrot
 
 
-def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxsize):
+def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxsize, baryon_mass_from_parts=True):
     """
     Gas, star and baryon (gas + star) kinematics of a selection, written into `out`:
     centres of mass and velocities, angular momenta about the component's own centre-of-mass velocity,
@@ -742,7 +742,10 @@ def baryon_kinematics(out, mass, position, velocity, types, radius, centre, boxs
             _, kappa, Mcr = angular_momentum_and_kappa_corot(mass[sel], position[sel], velocity[sel], vc, True)
             out[f"kappa_corot_{key}"] = kappa
             out[f"DtoT{key}"] = 1.0 - 2.0 * Mcr / M
-    Mb = mass[bar].sum()
+    # the baryon mass: Mgas + Mstar in the aperture and subhalo classes (aperture_properties.py:535-539, subhalo_properties.py:1861-1865,
+    # :2330-2334), one sum over the gas and star particles in the SO class (SO_properties.py:1240-1244) -- the same number in float64
+    # once stored, not the same float32 number when the snapshot's masses are float32
+    Mb = (mass[gas].sum() + mass[star].sum()) if baryon_mass_from_parts else mass[bar].sum()
     if Mb != 0:
         fb = mass[bar] / Mb
         vcb = (fb[:, None] * velocity[bar]).sum(axis=0)
@@ -1110,7 +1113,7 @@ class SOProperties:
             fdm = mass[dm] / M_t[1]
             vcom_dm = (fdm[:, None] * velocity[dm]).sum(axis=0)
             out["Ldm"] = get_angular_momentum(mass[dm], position[dm], velocity[dm], vcom_dm)
-        baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize)
+        baryon_kinematics(out, mass, position, velocity, types, radius, centre, u.boxsize, baryon_mass_from_parts=False)
         if self.virial_definition:
             for key, rr in (("concentration_unsoft", radius),
                             ("concentration_soft", np.maximum(softening, radius))):  # fmt: skip

@@ -416,6 +416,9 @@ void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *par
 void soap_launch_small_1024d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_128i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_512i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+// the variants for chunks with gas / stars / black holes (per-type moments, five half-mass classes, rotation, projected apertures)
+void soap_launch_small_128h(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
+void soap_launch_small_512h(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_stage_a(hipStream_t stream, const RunParams *params, SlabDev arena, const int *todo, long long n_todo);
 void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev arena, long long nlarge, long long ntiles, long long ngblocks,
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
@@ -835,6 +838,7 @@ struct TypeHost {
     Pay *pay = nullptr;
     double pos_min[3], pos_max[3], cell_size[3];
     double mean_mass = 0.0;
+    int vbytes = 8;    // width of the Masses / Velocities this type was staged with (8 or 4)
     unsigned *thin_off[2] = {nullptr, nullptr};
     double *thin_xyz[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     size_t thin_cap[2] = {0, 0};
@@ -857,6 +861,7 @@ struct TypeHost {
 #define SMALL_MAXG512 (256 * 11)    // most persistent waves of the 512- / 1024-entry variants (slices of the streamed-column buffer)
 #define SMALL_MAXG1024 (256 * 8)
 #define SMALL_MAXG128 (256 * 24)
+#define SMALL_MAXPJ 8    // projected apertures the hydro variants of the small-halo kernels hold (SMAXPJ of small_halo.hip)
 struct soap_engine {
     soap_engine_config cfg;
     hipStream_t stream = nullptr;
@@ -1339,6 +1344,7 @@ static int32_t stage_type(soap_engine *h, int32_t ts, int64_t n, const double *p
         T.res = resolution;
         T.n = n;
         T.grnr64 = grnr_bytes == 8;
+        T.vbytes = value_bytes;
         const long long ncell = (long long)resolution * resolution * resolution;
 
         unsigned *d_cell, *d_count, *d_rank, *d_tilesum;
@@ -1662,6 +1668,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     { const char *e = getenv("SOAP_ENGINE_PROFILE"); P.profile = e ? atoi(e) : 0; }
     P.hydro = (h->t[0].n > 0 || h->t[2].n > 0) ? 1 : 0;
     P.has_nu = h->t[NU_SLOT].n > 0 ? 1 : 0;
+    // float32 Masses in every staged type: the SO mass profile goes through the reference's float32 casts (SO_properties.py:400-402);
+    // a chunk that mixes widths concatenates to float64 in the reference, as here
+    P.mass_f32 = 1;
+    for (int t = 0; t < NT_ALL; t++) if (h->t[t].n > 0 && h->t[t].vbytes != 4) P.mass_f32 = 0;
+    if (ntot == 0) P.mass_f32 = 0;
     P.dm_only = (h->t[0].n == 0 && h->t[2].n == 0 && h->t[3].n == 0 && !P.has_nu) ? 1 : 0;
     P.target_density = target_density;
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
@@ -1904,15 +1915,22 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // leaves out stay on the general path altogether.
     std::vector<int> todo_small[NSV];
     const long long small_ns[NSV] = {128, 512, 1024};
+    bool small_hydro = false;
     {
-        bool small_ok = !P.has_nu && !P.literal && !want_property_radius && P.dm_only && h->probe_row < 0 && n_calcs <= MAXCALC &&
+        bool small_ok = !P.has_nu && !P.literal && !want_property_radius && h->probe_row < 0 && n_calcs <= MAXCALC &&
                         P.profile != 1 && h->cfg.slab_capacity <= 0;
-        int n_tensor_calcs = 0;   // (the inertia pass of the small-halo kernels holds the states of up to 16 calculations in its 64 lanes)
+        // chunks with gas / stars / black holes use the variants with the typed passes (k_small128h / k_small512h: per-type moments, five
+        // half-mass classes, rotation, projected apertures of up to SMALL_MAXPJ radii); they have no inertia tensor pass
+        small_hydro = !P.dm_only;
+        if (small_hydro && want_inertia) small_ok = false;
+        int n_tensor_calcs = 0, n_projected = 0;   // (the inertia pass of the small-halo kernels holds the states of up to 16 calculations in its 64 lanes)
         for (int c = 0; c < n_calcs; c++) {
-            if (calcs[c].kind == SOAP_CALC_PROJECTED || (calcs[c].flags & SOAP_CALC_FLAG_ROTATION)) small_ok = false;
+            if (calcs[c].kind == SOAP_CALC_PROJECTED) n_projected++;
+            if (!small_hydro && (calcs[c].kind == SOAP_CALC_PROJECTED || (calcs[c].flags & SOAP_CALC_FLAG_ROTATION))) small_ok = false;
             if ((calcs[c].flags & SOAP_CALC_FLAG_INERTIA) && calcs[c].kind <= SOAP_CALC_SO_MULTIPLE) n_tensor_calcs++;
         }
-        if (n_tensor_calcs > 16) small_ok = false;
+        if (n_tensor_calcs > 16 || n_projected > SMALL_MAXPJ) small_ok = false;
+        if (small_hydro && getenv("SOAP_ENGINE_SMALL_HYDRO") && atoi(getenv("SOAP_ENGINE_SMALL_HYDRO")) == 0) small_ok = false;
         if (want_inertia && getenv("SOAP_ENGINE_SMALL_INERTIA") && atoi(getenv("SOAP_ENGINE_SMALL_INERTIA")) == 0) small_ok = false;
         // SOAP_ENGINE_SMALL: 0 off; 4 (default) EVERY halo of the wavefront class goes through the small-halo kernels -- the
         // 128-entry one where the bound-particle count says so, the 512-entry one otherwise -- and what does not fit is handed on
@@ -1928,7 +1946,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // takes 11 560 halos and halves the hand-overs (11 865 -> 6 404, clean-up launch 5.1 -> 3.7 ms), and the halo phase stays at
             // 18.3 - 18.7 ms (rank of 8: 7.3 / 6.0 / 8.0 ms either way) -- the phase ends with the 256-thread class, not with the
             // clean-up.  SOAP_ENGINE_SMALL1024=1 switches it on; it has no tensor pass.
-            const bool use1024 = !want_inertia && getenv("SOAP_ENGINE_SMALL1024") && atoi(getenv("SOAP_ENGINE_SMALL1024")) != 0;
+            const bool use1024 = !want_inertia && !small_hydro && getenv("SOAP_ENGINE_SMALL1024") && atoi(getenv("SOAP_ENGINE_SMALL1024")) != 0;
             std::vector<int> rest;
             rest.reserve(todo[0].size());
             // A halo that is certain to outgrow the largest LDS slab in use is done by the wavefront class after the small-halo
@@ -1944,7 +1962,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : (pred <= (double)small_ns[2] && use1024 ? 2 : -1));
                 if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry / the 1024-entry variant)
                 if (small_mode == 3) v = 1;
-                if (small_mode == 5 && !want_inertia) v = 2;
+                if (small_mode == 5 && !want_inertia && !small_hydro) v = 2;
                 if (small_mode == 4 && v < 0) v = use1024 ? 2 : 1;   // (every halo of the class through the small-halo kernels: what does not fit is handed on)
                 if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
@@ -1994,6 +2012,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     h->ms_host_classify = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
     int groups_small[NSV] = {256 * 11, 256 * 8, 256 * 6};   // (14 KB of LDS per wave: eleven waves per CU; the 512-entry variant holds 236 registers: eight; the 1024-entry one 25 KB of LDS: six)
     if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
+    if (small_hydro) groups_small[0] = groups_small[1] = 256 * 8;   // (256 registers per wave: two waves per SIMD)
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
     { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
     // every persistent wave of the 512- / 1024-entry variants owns a slice of the streamed-column buffer: never more waves than slices
@@ -2017,7 +2036,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipEventRecord(C.start, cs));
         C.nh += nt;
         const int ng = (int)std::min<long long>(groups_small[v], nt);
-        if (want_inertia) {   // the variants with the inertia tensor pass (more LDS per wave: fewer waves per CU)
+        if (small_hydro) {    // chunks with gas / stars / black holes
+            if (v == 0) soap_launch_small_128h(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+            else soap_launch_small_512h(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+        } else if (want_inertia) {   // the variants with the inertia tensor pass (more LDS per wave: fewer waves per CU)
             if (v == 0) soap_launch_small_128i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
             else soap_launch_small_512i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
         } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);

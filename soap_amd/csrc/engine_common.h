@@ -192,6 +192,8 @@ struct RunParams {
     int hydro;             // gas or star particles staged: the baryon kinematics are computed
     int dm_only;           // only dark matter staged
     int has_nu;            // neutrino particles staged
+    int mass_f32;          // every staged mass array is float32: the SO mass profile is then the float64 cumulative mass cast back to
+                           // float32, as the reference computes it (SO_properties.py:400-402: cumsum(dtype=float64).astype(mass.dtype))
     double soft[SOAP_NTYPES];
     int ncalc;
     long long ncols;

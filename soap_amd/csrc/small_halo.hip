@@ -36,6 +36,7 @@
 #define SGLOBAL 0              // 1: the columns that only the property passes stream (mass, offsets, velocities: 56 of the 81 bytes of an
 #endif                         // entry) live in a slice of global memory that belongs to the wave, the slab of a 512-entry halo takes 11 KB of LDS
 #define SPREFB 12              // calculations whose prefix moments are finalised together
+#define SMAXPJ 8               // projected apertures per run in the hydro variants (engine.hip keeps longer lists on the general path)
 #if SHYDRO
 #define SMOM A_NSUM
 #define SNHM NHM
@@ -84,10 +85,14 @@ struct SmallWave {
 #if SINERTIA
     double it_par[64][12];        // inertia tensors: eigenvectors (9) and reciprocal semi-axes (3) of the 64 states, read by every lane in the sweeps
 #endif
+#if SHYDRO
+    double rot_v[MAXCALC][6];     // centre-of-mass velocities of gas (0..2) and stars (3..5) per calculation, slab frame (parked by finalize_moments for the rotation pass)
+    double pj[SMAXPJ][24];        // prefix sums of the projected apertures of one axis, in order of radius
+#endif
     // per-halo context, named as in halo_kernel.inc (the shared includes read them through g_S)
     double c[3], L, shift[3];
     double nu_density, a, mpc, mpc20, G_eff;
-    int hydro, has_nu;
+    int hydro, has_nu, mass_f32;
     unsigned ticket;   // queue position of the halo the wave is working on
 #ifdef SMALL_CHECK
     unsigned long long *dbg;
@@ -152,15 +157,22 @@ SOAP_DEV double small_dens(int i) {
     const double nuK = ((g_S.nu_density * 4.0) / 3.0) * M_PI;
     const double K43 = (4.0 / 3.0) * M_PI;
     const double r3 = cube(g_W.r[i]);
-    return (g_W.cum[i] + nuK * r3) / (K43 * r3);
+    // (with float32 masses: the reference's casts of the cumulative mass, so_cum_nu of halo_so_eval.inc)
+    const double c = g_W.mass_f32 ? (double)(float)g_W.cum[i] : g_W.cum[i];
+    const double cn = (g_W.mass_f32 && nuK != 0.0) ? (double)(float)(c + nuK * r3) : c + nuK * r3;
+    return cn / (K43 * r3);
 }
 #define SV_R(i) g_W.r[i]
-#define SV_CUM(i) g_W.cum[i]
+#define SV_CUM(i) so_cum32(g_W.cum[i])
 #define SV_DENS(i) small_dens(i)
 #define RES_OK 0
 #define RES_TOO_SMALL 1
 #include "halo_so_eval.inc"
-#define FZ_PARK_ROT(c, d, vg, vs) { }   // (no rotation pass in this class: engine.hip keeps such runs on the general path)
+#if SHYDRO
+#define FZ_PARK_ROT(c, d, vg, vs) { g_W.rot_v[c][d] = (vg); g_W.rot_v[c][3 + (d)] = (vs); }
+#else
+#define FZ_PARK_ROT(c, d, vg, vs) { }   // (no gas or stars in this variant)
+#endif
 // log10 / 10**x of the concentration as real calls: inlined, the two library routines hold ~100 registers at their peak and push
 // the kernel's long-lived values into scratch
 #ifdef SMALL_INLINE_MATH
@@ -190,7 +202,7 @@ SOAP_DEV int mask_next(const Mask256 &m, int from, int want) {
 
 // candidate cells of type `T` along the three axes for a sphere of radius R about the halo centre (shared_mesh.py:146-179):
 // lane d < 3 works on axis d, every lane gets all three masks
-SOAP_DEV void cell_masks(const CAS TypeDev &T, double R, Mask256 &mx, Mask256 &my, Mask256 &mz) {
+SOAP_DEV void cell_masks(const CAS TypeDev &T, double R, Mask256 &mx, Mask256 &my, Mask256 &mz, bool *nowrap = nullptr) {
     const int d = LANE < 2 ? LANE : 2;
     const double pmin = d == 0 ? T.pos_min[0] : (d == 1 ? T.pos_min[1] : T.pos_min[2]);
     const double pmax = d == 0 ? T.pos_max[0] : (d == 1 ? T.pos_max[1] : T.pos_max[2]);
@@ -211,6 +223,9 @@ SOAP_DEV void cell_masks(const CAS TypeDev &T, double R, Mask256 &mx, Mask256 &m
         const int ihi = qhi < -1.0 ? -1 : (qhi > (double)(res - 1) ? res - 1 : (int)qhi);
         if (ilo <= ihi) mk.set_range(ilo, ihi);
     }
+    // no periodic copy of the sphere reaches the mesh along any axis and every candidate lies within L/2 of the centre (R + one cell):
+    // the minimum-image separation of the mesh query is then x - c itself (shared_mesh.py:138-142 changes nothing)
+    if (nowrap) *nowrap = __ballot(LANE < 3 && (min_copy != 0 || max_copy != 0 || !(R + 1.5 * csz <= 0.5 * L))) == 0ull;
 #define BC64(w, l) ((unsigned long long)(unsigned)rl((int)(unsigned)(w), l) | ((unsigned long long)(unsigned)rl((int)(unsigned)((w) >> 32), l) << 32))
     mx.w0 = BC64(mk.w0, 0); mx.w1 = BC64(mk.w1, 0); mx.w2 = BC64(mk.w2, 0); mx.w3 = BC64(mk.w3, 0);
     my.w0 = BC64(mk.w0, 1); my.w1 = BC64(mk.w1, 1); my.w2 = BC64(mk.w2, 1); my.w3 = BC64(mk.w3, 1);
@@ -252,7 +267,8 @@ __device__ __forceinline__ int small_select(const CAS RunParams &P, double R) {
         if (T.n == 0) continue;
         const int res = T.res;
         Mask256 mx, my, mz;
-        cell_masks(T, R, mx, my, mz);
+        bool nowrap;
+        cell_masks(T, R, mx, my, mz, &nowrap);
         unsigned long long run_lo, run_hi;
         const int nrun = small_x_runs(mx, res, run_lo, run_hi);
         const int nk = mz.count(), nj = my.count();
@@ -295,7 +311,9 @@ __device__ __forceinline__ int small_select(const CAS RunParams &P, double R) {
                     for (int u = 0; u < SEL_UT; u++) {
                         bool sel = false;
                         if (pp[u] < end) {
-                            const double ax = min_image(xx[u], cx, L), ay = min_image(yy[u], cy, L), az = min_image(zz[u], cz, L);
+                            double ax, ay, az;
+                            if (nowrap) { ax = xx[u] - cx; ay = yy[u] - cy; az = zz[u] - cz; }
+                            else { ax = min_image(xx[u], cx, L); ay = min_image(yy[u], cy, L); az = min_image(zz[u], cz, L); }
                             const double r2 = (ax * ax + ay * ay) + az * az;
                             sel = r2 <= R2;
                         }
@@ -699,7 +717,8 @@ struct MomOut {       // what the later passes need of a calculation's prefix mo
     double MV[3];     // sum m v' (slab frame)
 };
 __device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_family, const soap_calc_desc &cd, int coloff, const CalcState &cs,
-                                              bool in, int rank, int m, double soft1, double *nfar, MomOut *mo) {
+                                              bool in, int rank, int m, const double (&soft)[4], double *nfar, MomOut *mo) {
+    const double soft1 = soft[1]; (void)soft1;
     *nfar = 0.0;
     for (int t = 0; t < 4; t++) mo->M[t] = 0.0;
     mo->N1 = 0.0; mo->MV[0] = mo->MV[1] = mo->MV[2] = 0.0;
@@ -802,7 +821,83 @@ __device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_fa
         }
         __builtin_amdgcn_sched_barrier(0);
 #else
-#error "SHYDRO variant: not built yet"
+        // chunks with gas / stars / black holes: the full moment set of halo_kernel.inc's reduce_range (counts and masses per type
+        // slot, the all-particle sums, then momentum / position / angular momentum / velocity products of the dark matter, the gas
+        // and the stars), as inclusive wave scans in five sweeps of at most 15 running sums
+#define SMALL_SWEEP(NL, IMAX, FILL, STORE)                                                                                   \
+        {                                                                                                                        \
+            double carry[NL];                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < NL; a++) carry[a] = 0.0;                                                       \
+            _Pragma("unroll 1") for (int base = 0; base < nmax; base += 64) {                                                    \
+                const int i = base + LANE;                                                                                       \
+                double c[NL];                                                                                                    \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) c[a] = 0.0;                                                       \
+                if (i < nmax) {                                                                                                  \
+                    const unsigned char fl = g_W.flags[i];                                                                       \
+                    const int t = fl & FL_TYPE;                                                                                  \
+                    if (!bound_family || (fl & FL_BOUND)) { FILL }                                                               \
+                }                                                                                                                \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) {                                                                 \
+                    if (a == IMAX) c[a] = fmax(wave_scan_max(c[a]), carry[a]);                                                   \
+                    else c[a] = wave_scan(c[a], LANE) + carry[a];                                                                \
+                    if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                         \
+                }                                                                                                                \
+                for (int k = k0; k < k1; k++) {                                                                                  \
+                    const int nc = rl(my_nc, k);                                                                                 \
+                    if (nc > base && nc <= base + 64 && LANE == nc - 1 - base) { double *dst = g_W.prefc[k - k0]; STORE }        \
+                }                                                                                                                \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) carry[a] = rl64(c[a], 63);                                        \
+            }                                                                                                                    \
+            LAST                                                                                                                 \
+        }                                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);
+#define LAST
+#define SW_FILL_ { const double mm = CX(m)[i], r = g_W.r[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i]; \
+              c[0] = t == 0 ? 1.0 : 0.0; c[1] = t == 1 ? 1.0 : 0.0; c[2] = t == 2 ? 1.0 : 0.0; c[3] = t == 3 ? 1.0 : 0.0; \
+              c[4] = t == 0 ? mm : 0.0; c[5] = t == 1 ? mm : 0.0; c[6] = t == 2 ? mm : 0.0; c[7] = t == 3 ? mm : 0.0; \
+              c[8] = mm * x; c[9] = mm * y; c[10] = mm * z; c[11] = mm * r; }
+#define SW_STORE_ { dst[A_N0] = c[0]; dst[A_N1] = c[1]; dst[A_N2] = c[2]; dst[A_N3] = c[3]; \
+              dst[A_M0] = c[4]; dst[A_M1] = c[5]; dst[A_M2] = c[6]; dst[A_M3] = c[7]; \
+              dst[A_MX] = c[8]; dst[A_MX + 1] = c[9]; dst[A_MX + 2] = c[10]; dst[A_MR] = c[11]; }
+        SMALL_SWEEP(12, -1, SW_FILL_, SW_STORE_)
+#undef SW_FILL_
+#undef SW_STORE_
+#undef LAST
+#define LAST *nfar = carry[9];
+#define SW_FILL_ { const double mm = CX(m)[i], r = g_W.r[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i]; \
+              const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i]; \
+              c[0] = mm * u; c[1] = mm * v; c[2] = mm * w; \
+              c[3] = mm * (y * w - z * v); c[4] = mm * (z * u - x * w); c[5] = mm * (x * v - y * u); \
+              c[6] = mm * fmax(t == 0 ? soft[0] : (t == 1 ? soft[1] : (t == 2 ? soft[2] : soft[3])), r); \
+              c[7] = (fl & FL_SAT) ? mm : 0.0; c[8] = (fl & FL_EXT) ? mm : 0.0; c[9] = (r > 1e-8) ? 1.0 : 0.0; c[10] = r; }
+#define SW_STORE_ { dst[A_MV] = c[0]; dst[A_MV + 1] = c[1]; dst[A_MV + 2] = c[2]; \
+              dst[A_LA] = c[3]; dst[A_LA + 1] = c[4]; dst[A_LA + 2] = c[5]; \
+              dst[A_MRS] = c[6]; dst[A_MSAT] = c[7]; dst[A_MEXT] = c[8]; dst[A_NFAR] = c[9]; dst[A_RMAX] = c[10]; }
+        SMALL_SWEEP(11, 10, SW_FILL_, SW_STORE_)
+#undef SW_FILL_
+#undef SW_STORE_
+#undef LAST
+#define LAST
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {
+            // momentum, position, angular momentum and velocity products of one component: dark matter, gas, stars
+            const int want_t = pass == 0 ? 1 : (pass == 1 ? 0 : 2);
+            const int b_mv = pass == 0 ? A_MVD : (pass == 1 ? A_GMV : A_SMV), b_mx = pass == 0 ? A_MXD : (pass == 1 ? A_GMX : A_SMX);
+            const int b_l = pass == 0 ? A_LD : (pass == 1 ? A_GL : A_SL), b_vv = pass == 0 ? A_VV : (pass == 1 ? A_GVV : A_SVV);
+#define SW_FILL_ { if (t == want_t) { \
+                    const double mm = CX(m)[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i]; \
+                    const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i]; \
+                    c[0] = mm * u; c[1] = mm * v; c[2] = mm * w; c[3] = mm * x; c[4] = mm * y; c[5] = mm * z; \
+                    c[6] = mm * (y * w - z * v); c[7] = mm * (z * u - x * w); c[8] = mm * (x * v - y * u); \
+                    c[9] = mm * u * u; c[10] = mm * v * v; c[11] = mm * w * w; c[12] = mm * u * v; c[13] = mm * u * w; c[14] = mm * v * w; } }
+#define SW_STORE_ { for (int d = 0; d < 3; d++) { dst[b_mv + d] = c[d]; dst[b_mx + d] = c[3 + d]; dst[b_l + d] = c[6 + d]; } \
+                  for (int d = 0; d < 6; d++) dst[b_vv + d] = c[9 + d]; }
+            SMALL_SWEEP(15, -1, SW_FILL_, SW_STORE_)
+#undef SW_FILL_
+#undef SW_STORE_
+        }
+#undef LAST
+#undef SMALL_SWEEP
 #endif
         WSYNC();
         if (in && rank >= k0 && rank < k1) {
@@ -826,8 +921,9 @@ __device__ __forceinline__ void small_moments(GAS double *rowbase, bool bound_fa
 // of M(<r) / max(r, softening), first maximum) at the end of every selection, the unsoftened v_max of the bound subhalo
 // (subhalo_properties.py:994-996), half-mass radii (half_mass_radius.py:40-80) -- then finalize_scan with lanes = calculations
 __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_family, const soap_calc_desc &cd, int coloff, const CalcState &cs,
-                                           bool in, int m, const MomOut &mo, double soft1, double nfar_total, double nbound_total,
+                                           bool in, int m, const MomOut &mo, const double (&soft)[4], double nfar_total, double nbound_total,
                                            double *vs_out, double *rs_out) {
+    const double soft1 = soft[1]; (void)soft1;
     *vs_out = -1.0; *rs_out = 0.0;
     if (m == 0) return;
     const int nmax = rl(LANE < m ? g_W.bnd[LANE < m ? LANE : 0] : 0, m - 1);
@@ -839,6 +935,12 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
         const double Mtot = ((mo.M[0] + mo.M[1]) + mo.M[2]) + mo.M[3];
         if (cd.kind == SOAP_CALC_SUBHALO) { tg[0] = 0.5 * Mtot; tg[1] = 0.5 * mo.M[1]; }
         else if (cd.kind == SOAP_CALC_APERTURE_INCL || cd.kind == SOAP_CALC_APERTURE_EXCL) tg[1] = 0.5 * mo.M[1];
+#if SHYDRO
+        // ... [2] gas, [3] stars, [4] baryons (aperture_properties.py:3469-3548, subhalo_properties.py:2265-2334)
+        if (cd.kind == SOAP_CALC_SUBHALO || cd.kind == SOAP_CALC_APERTURE_INCL || cd.kind == SOAP_CALC_APERTURE_EXCL) {
+            tg[2] = 0.5 * mo.M[0]; tg[3] = 0.5 * mo.M[2]; tg[4] = 0.5 * (mo.M[0] + mo.M[2]);
+        }
+#endif
     }
     double hm[SNHM];
 #pragma unroll
@@ -846,6 +948,9 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
     const bool want_unsoft = bound_family;
     const bool allclose = bound_family && nbound_total > 0.0 && nfar_total == 0.0;
     double carryA = 0.0, carryB = 0.0, carryC = 0.0, carryV = -1.0, carryS = 0.0;
+#if SHYDRO
+    double carryG = 0.0, carryT = 0.0;   // cumulative gas / stellar mass
+#endif
     double bestU = -1.0, bestUr = 0.0;
     long long bestUi = 0x7fffffffffffffffLL;
     double my_vs = -1.0, my_rs = 0.0;
@@ -865,6 +970,7 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
         const double sA = wave_scan(mm, LANE) + carryA;
 #if SHYDRO
         const double sB = wave_scan((t == 1) ? mm : 0.0, LANE) + carryB;
+        const double sG = wave_scan((t == 0) ? mm : 0.0, LANE) + carryG, sT = wave_scan((t == 2) ? mm : 0.0, LANE) + carryT;
 #else
         const double sB = sA;
 #endif
@@ -872,7 +978,11 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
         // ---- v_max: this particle's candidate, the running arg-max up to it (ties keep the lower index)
         double wv = -1.0, ws = 0.0;
         if (mem) {
-            const double sr = fmax(soft1, r);   // (SHYDRO: the softening of the particle's type)
+#if SHYDRO
+            const double sr = fmax(t == 0 ? soft[0] : (t == 1 ? soft[1] : (t == 2 ? soft[2] : soft[3])), r);   // the softening of the particle's type
+#else
+            const double sr = fmax(soft1, r);
+#endif
             if (sr > 1e-8) { wv = sA / sr; ws = sr; }
             if (want_unsoft) {
                 const double rank = sC - 1.0;   // members before this one; nskip = 1 (subhalo_properties.py:994-996)
@@ -896,6 +1006,17 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
         // is switched off delivers zero -- lane 1 would see no mass before it)
         const double shA = dpp_f64<DPP_WAVE_SHR1>(sA), shB = dpp_f64<DPP_WAVE_SHR1>(sB);
         const double pA = LANE == 0 ? carryA : shA, pB = LANE == 0 ? carryB : shB;
+#if SHYDRO
+        const double shG = dpp_f64<DPP_WAVE_SHR1>(sG), shT = dpp_f64<DPP_WAVE_SHR1>(sT);
+        const double pG = LANE == 0 ? carryG : shG, pT = LANE == 0 ? carryT : shT;
+#define SHM_CV(w) ((w) == 0 ? sA : ((w) == 1 ? sB : ((w) == 2 ? sG : ((w) == 3 ? sT : sG + sT))))
+#define SHM_PV(w) ((w) == 0 ? pA : ((w) == 1 ? pB : ((w) == 2 ? pG : ((w) == 3 ? pT : pG + pT))))
+#define SHM_CLS(w, tt) ((w) == 0 || ((w) == 1 && (tt) == 1) || ((w) == 2 && (tt) == 0) || ((w) == 3 && (tt) == 2) || ((w) == 4 && ((tt) == 0 || (tt) == 2)))
+#else
+#define SHM_CV(w) ((w) == 0 ? sA : sB)
+#define SHM_PV(w) ((w) == 0 ? pA : pB)
+#define SHM_CLS(w, tt) ((w) == 0 || (tt) == 1)
+#endif
 #pragma unroll
         for (int w = 0; w < SNHM; w++) {
             unsigned long long open = __ballot(in && tg[w] > 0.0 && my_n > base);
@@ -904,19 +1025,19 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
                 open &= open - 1;
                 const double tgt = rl64(tg[w], c2);
                 const int n2 = rl(my_n, c2);
-                const double cv = w == 0 ? sA : sB;
-                const bool cls = w == 0 || t == 1;
+                const double cv = SHM_CV(w);
+                const bool cls = SHM_CLS(w, t);
                 const unsigned long long hit = __ballot(mem && cls && i < n2 && cv >= tgt);
                 if (!hit) continue;
                 const int owner = __ffsll((long long)hit) - 1;
                 // this particle is the first whose cumulative weight reaches the target (half_mass_radius.py:40-80); what is
                 // known about it is made uniform and every lane computes the same radius (no value that exists in one lane only)
                 const double cv_o = rl64(cv, owner), r_o = rl64(r, owner);
-                double Wmin = rl64(w == 0 ? pA : pB, owner), rmin = 0.0;
+                double Wmin = rl64(SHM_PV(w), owner), rmin = 0.0;
                 int j = base + owner - 1;   // previous member of the same class
                 while (j >= 0) {
                     const unsigned char fj = g_W.flags[j];
-                    if ((!bound_family || (fj & FL_BOUND)) && (w == 0 || (fj & FL_TYPE) == 1)) break;
+                    if ((!bound_family || (fj & FL_BOUND)) && SHM_CLS(w, fj & FL_TYPE)) break;
                     j--;
                 }
                 if (j < 0) Wmin = 0.0; else rmin = g_W.r[j];
@@ -926,7 +1047,13 @@ __device__ __forceinline__ void small_scan(GAS double *rowbase, bool bound_famil
         }
         carryA = rl64(sA, 63); carryB = rl64(sB, 63); carryC = rl64(sC, 63);
         carryV = rl64(wv, 63); carryS = rl64(ws, 63);
+#if SHYDRO
+        carryG = rl64(sG, 63); carryT = rl64(sT, 63);
+#endif
     }
+#undef SHM_CV
+#undef SHM_PV
+#undef SHM_CLS
     double vu = -1.0, ru = 0.0;
     if (want_unsoft) {
         // arg-max over all bound members, first maximum: largest value, then the smallest index
@@ -1295,6 +1422,302 @@ __device__ __attribute__((noinline)) void small_inertia(GAS double *row, int kin
 }
 #endif   // SINERTIA
 
+#if SHYDRO
+// ======================= ordered rotation of gas / stars / baryons (rotation_pass of halo_kernel.inc on one wave) ========
+// kappa_corot and the disc fractions (kinematic_properties.py:266-425): per flagged calculation one sweep over its members
+// with lanes = particles; the components' centre-of-mass velocities were parked by finalize_moments, their angular momenta
+// are in the row.
+__device__ __forceinline__ void small_rotation(GAS double *row, const soap_calc_desc &cd, int coloff, const CalcState &cs, int ncalc) {
+    unsigned long long todo = __ballot(LANE < ncalc && (cd.flags & SOAP_CALC_FLAG_ROTATION) && cs.state == 1 && cd.kind != SOAP_CALC_PROJECTED);
+    if (!todo) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows were written by other lanes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    WSYNC();
+#pragma unroll 1
+    while (todo) {
+        const int c2 = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int kind = rl(cd.kind, c2), n_in = rl(cs.n, c2);
+        int cMg, cMs, cNg, cNs, cLg, cLs, cLb, cKap, cDt;
+        bool bound_only = false;
+        if (kind == SOAP_CALC_SUBHALO) { cNg = SH_Ngas; cNs = SH_Nstar; cMg = SH_Mgas; cMs = SH_Mstar; cLg = SH_Lgas; cLs = SH_Lstar; cLb = SH_Lbaryons; cKap = SH_kappa; cDt = SH_DtoT; bound_only = true; }
+        else if (kind == SOAP_CALC_APERTURE_INCL || kind == SOAP_CALC_APERTURE_EXCL) {
+            cNg = AP_Ngas; cNs = AP_Nstar; cMg = AP_Mgas; cMs = AP_Mstar; cLg = AP_Lgas; cLs = AP_Lstar; cLb = AP_Lbaryons; cKap = AP_kappa; cDt = AP_DtoT;
+            bound_only = kind == SOAP_CALC_APERTURE_EXCL;
+        } else { cNg = SOC_Ngas; cNs = SOC_Nstar; cMg = SOC_Mgas; cMs = SOC_Mstar; cLg = SOC_Lgas; cLs = SOC_Lstar; cLb = SOC_Lbaryons; cKap = -1; cDt = SOC_DtoT; }
+        GAS double *crow = row + rl(coloff, c2);
+        const double Mg = uni(crow[cMg]), Ms = uni(crow[cMs]);
+        if (Mg == 0.0 && Ms == 0.0) continue;
+        // centre-of-mass velocities (slab frame), unit vectors along L and |L| of gas, stars, baryons
+        double vc[3][3], hh[3][3], ln[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int cl = q == 0 ? cLg : (q == 1 ? cLs : cLb);
+            const double lx = uni(crow[cl]), ly = uni(crow[cl + 1]), lz = uni(crow[cl + 2]);
+            const double nn = sqrt((lx * lx + ly * ly) + lz * lz);
+            ln[q] = nn;
+            hh[q][0] = nn > 0.0 ? lx / nn : 0.0; hh[q][1] = nn > 0.0 ? ly / nn : 0.0; hh[q][2] = nn > 0.0 ? lz / nn : 0.0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const double vg = g_W.rot_v[c2][d], vs = g_W.rot_v[c2][3 + d];
+                vc[q][d] = q == 0 ? vg : (q == 1 ? vs : (Mg * vg + Ms * vs) / (Mg + Ms));
+            }
+        }
+        double sg[3] = {0.0, 0.0, 0.0}, ss[3] = {0.0, 0.0, 0.0}, sb[2] = {0.0, 0.0};
+#pragma unroll 1
+        for (int base = 0; base < n_in; base += 64) {
+            const int i = base + LANE;
+            if (i >= n_in) continue;
+            const int fl = g_W.flags[i];
+            const int t = fl & FL_TYPE;
+            if ((t != 0 && t != 2) || (bound_only && !(fl & FL_BOUND))) continue;
+            const double m = CX(m)[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i];
+            const double u0 = CX(vx)[i], u1 = CX(vy)[i], u2 = CX(vz)[i];
+            const double r2 = (x * x + y * y) + z * z;
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int q = pass == 0 ? (t == 0 ? 0 : 1) : 2;
+                const double v0 = q == 0 ? vc[0][0] : (q == 1 ? vc[1][0] : vc[2][0]), v1 = q == 0 ? vc[0][1] : (q == 1 ? vc[1][1] : vc[2][1]),
+                             v2 = q == 0 ? vc[0][2] : (q == 1 ? vc[1][2] : vc[2][2]);
+                const double h0 = q == 0 ? hh[0][0] : (q == 1 ? hh[1][0] : hh[2][0]), h1 = q == 0 ? hh[0][1] : (q == 1 ? hh[1][1] : hh[2][1]),
+                             h2 = q == 0 ? hh[0][2] : (q == 1 ? hh[1][2] : hh[2][2]);
+                const double a = u0 - v0, b = u1 - v1, w = u2 - v2;
+                const double l0 = m * (y * w - z * b), l1 = m * (z * a - x * w), l2 = m * (x * b - y * a);
+                const double Li = (l0 * h0 + l1 * h1) + l2 * h2;
+                const double rdotL = (x * h0 + y * h1) + z * h2;
+                const double Ri2 = r2 - rdotL * rdotL;
+                const double ke = (m * (a * a) + m * (b * b)) + m * (w * w);
+                const double kco = (Ri2 != 0.0 && Li > 0.0) ? 0.5 * ((Li * Li) / (m * Ri2)) : 0.0;
+                const double mc = Li < 0.0 ? m : 0.0;
+                if (pass == 1) { sb[0] += ke; sb[1] += kco; }
+                else if (t == 0) { sg[0] += ke; sg[1] += kco; sg[2] += mc; }
+                else { ss[0] += ke; ss[1] += kco; ss[2] += mc; }
+            }
+        }
+        const double p1 = wave_sum4(sg[0], sg[1], sg[2], ss[0]), p2 = wave_sum4(ss[1], ss[2], sb[0], sb[1]);
+        const double t0 = rl64(p1, 0), t1 = rl64(p1, 16), t2 = rl64(p1, 32), t3 = rl64(p1, 48);
+        const double t4 = rl64(p2, 0), t5 = rl64(p2, 16), t6 = rl64(p2, 32), t7 = rl64(p2, 48);
+        const double Ng = uni(crow[cNg]), Ns = uni(crow[cNs]);
+        if (LANE == 0) {
+            // a single member moves with its own centre-of-mass velocity: L = 0 exactly in the reference
+            const double cnt[3] = {Ng, Ns, Ng + Ns};
+            const double Mq[3] = {Mg, Ms, Mg + Ms};
+            const double Kq[3] = {0.5 * t0, 0.5 * t3, 0.5 * t6};
+            const double Cq[3] = {t1, t4, t7};
+            const double Cm[3] = {t2, t5, 0.0};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                if (Mq[q] == 0.0) continue;
+                const bool rot = cnt[q] > 1.0 && ln[q] > 0.0;
+                if (cKap >= 0) crow[cKap + q] = (rot && Kq[q] > 0.0) ? Cq[q] / Kq[q] : 0.0;
+                if (q < 2) crow[cDt + q] = 1.0 - 2.0 * (rot ? Cm[q] : 0.0) / Mq[q];
+            }
+        }
+    }
+}
+
+// ======================= projected apertures (projected_aperture_properties.py:98-198; projected_apertures of halo_kernel.inc) =====
+// Bound members only.  Per projection axis the members inside the largest requested aperture are ordered by their 2D radius
+// (register bitonic network on (radius, slab index), as the build's), so the apertures are nested prefixes: prefix sums by
+// wave scans with the lane that holds a prefix' last member storing them, finalisation with lanes = apertures, then one scan
+// for the half-mass radii in projection (:1491-1577).  The sorted radii / slab indices live in the cum / pidx columns of the
+// LDS slab, both dead after the radius loop.
+enum { SPJ_N0 = 0, SPJ_M0 = 4, SPJ_MX = 8, SPJ_MV = 11, SPJ_VL = 14, SPJ_VL2 = 15, SPJ_SMX = 16, SPJ_VLG = 19, SPJ_VL2G = 20, SPJ_VLS = 21, SPJ_VL2S = 22 };
+__device__ __forceinline__ void small_projected(GAS double *row, const soap_calc_desc &cd, int coloff, const CalcState &cs, int ncalc, int nsub) {
+    const bool isp = LANE < ncalc && cd.kind == SOAP_CALC_PROJECTED && cs.state == 1;
+    const unsigned long long pm = __ballot(isp);
+    if (!pm) return;
+    const double myR = isp ? cs.R : 0.0;
+    const double Rmax = wave_max(myR);
+    // position of this lane's aperture in order of radius
+    int rank = 0;
+    {
+        unsigned long long rest = pm;
+        while (rest) {
+            const int c2 = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const double R2 = rl64(myR, c2);
+            if (R2 < myR || (R2 == myR && c2 < LANE)) rank++;
+        }
+    }
+    int lg = 1;
+    while ((1 << lg) < nsub) lg++;
+#pragma unroll 1
+    for (int axis = 0; axis < 3; axis++) {
+        double key[SE];
+        unsigned idx[SE], dmy[SE];
+#pragma unroll
+        for (int e = 0; e < SE; e++) {
+            const int i = 64 * e + LANE;
+            key[e] = INFINITY; idx[e] = (unsigned)i; dmy[e] = 0u;
+            if (i < nsub && (g_W.flags[i] & FL_BOUND)) {
+                const double x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i];
+                const double rp = axis == 0 ? sqrt(y * y + z * z) : (axis == 1 ? sqrt(x * x + z * z) : sqrt(x * x + y * y));
+                if (rp <= Rmax) key[e] = rp;
+            }
+        }
+        int nmem = 0;
+#pragma unroll
+        for (int e = 0; e < SE; e++) nmem += __popcll(__ballot(key[e] < INFINITY));
+        if (nmem == 0) continue;
+        small_sort(key, idx, dmy, lg);
+        WSYNC();
+#pragma unroll
+        for (int e = 0; e < SE; e++) { g_W.cum[64 * e + LANE] = key[e]; g_W.pidx[64 * e + LANE] = idx[e]; }
+        // members with rp <= R of every aperture (projected_aperture_properties.py:140-142)
+        int my_nc = 0;
+        {
+            unsigned long long rest = pm;
+            while (rest) {
+                const int c2 = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const double Rc = rl64(myR, c2);
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < SE; e++) cnt += __popcll(__ballot(key[e] <= Rc));
+                if (LANE == c2) my_nc = cnt;
+            }
+        }
+        for (int e2 = LANE; e2 < SMAXPJ * 24; e2 += 64) (&g_W.pj[0][0])[e2] = 0.0;
+        WSYNC();
+        const int nmax = nmem;
+        // ---- prefix sums in two sweeps of 12 + 11 running sums
+#define SPJ_SWEEP(NL, FILL, STORE)                                                                                             \
+        {                                                                                                                        \
+            double carry[NL];                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < NL; a++) carry[a] = 0.0;                                                       \
+            _Pragma("unroll 1") for (int base = 0; base < nmax; base += 64) {                                                    \
+                const int p_ = base + LANE;                                                                                      \
+                double c[NL];                                                                                                    \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) c[a] = 0.0;                                                       \
+                if (p_ < nmax) {                                                                                                 \
+                    const int i = (int)g_W.pidx[p_];                                                                             \
+                    const int t = g_W.flags[i] & FL_TYPE;                                                                        \
+                    const double mm = CX(m)[i];                                                                                  \
+                    FILL                                                                                                         \
+                }                                                                                                                \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) { c[a] = wave_scan(c[a], LANE) + carry[a]; if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0); } \
+                {                                                                                                                \
+                    unsigned long long rest = pm;                                                                                \
+                    while (rest) {                                                                                               \
+                        const int c2 = __ffsll((long long)rest) - 1;                                                             \
+                        rest &= rest - 1;                                                                                        \
+                        const int nc = rl(my_nc, c2), rk = rl(rank, c2);                                                         \
+                        if (nc > base && nc <= base + 64 && LANE == nc - 1 - base) { double *dst = g_W.pj[rk]; STORE }           \
+                    }                                                                                                            \
+                }                                                                                                                \
+                _Pragma("unroll") for (int a = 0; a < NL; a++) carry[a] = rl64(c[a], 63);                                        \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);
+#define SW_FILL_ { const double x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i]; \
+              const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i]; \
+              const double vl = axis == 0 ? u : (axis == 1 ? v : w); \
+              c[0] = t == 0 ? 1.0 : 0.0; c[1] = t == 1 ? 1.0 : 0.0; c[2] = t == 2 ? 1.0 : 0.0; c[3] = t == 3 ? 1.0 : 0.0; \
+              c[4] = t == 0 ? mm : 0.0; c[5] = t == 1 ? mm : 0.0; c[6] = t == 2 ? mm : 0.0; c[7] = t == 3 ? mm : 0.0; \
+              c[8] = mm * x; c[9] = mm * y; c[10] = mm * z; c[11] = t == 1 ? mm * vl : 0.0; }
+#define SW_STORE_ { for (int d = 0; d < 8; d++) dst[SPJ_N0 + d] = c[d]; \
+              dst[SPJ_MX] = c[8]; dst[SPJ_MX + 1] = c[9]; dst[SPJ_MX + 2] = c[10]; dst[SPJ_VL] = c[11]; }
+        SPJ_SWEEP(12, SW_FILL_, SW_STORE_)
+#undef SW_FILL_
+#undef SW_STORE_
+#define SW_FILL_ { const double x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i]; \
+              const double u = CX(vx)[i], v = CX(vy)[i], w = CX(vz)[i]; \
+              const double vl = axis == 0 ? u : (axis == 1 ? v : w); \
+              c[0] = mm * u; c[1] = mm * v; c[2] = mm * w; c[3] = t == 1 ? mm * vl * vl : 0.0; \
+              c[4] = t == 2 ? mm * x : 0.0; c[5] = t == 2 ? mm * y : 0.0; c[6] = t == 2 ? mm * z : 0.0; \
+              c[7] = t == 0 ? mm * vl : 0.0; c[8] = t == 0 ? mm * vl * vl : 0.0; c[9] = t == 2 ? mm * vl : 0.0; c[10] = t == 2 ? mm * vl * vl : 0.0; }
+#define SW_STORE_ { dst[SPJ_MV] = c[0]; dst[SPJ_MV + 1] = c[1]; dst[SPJ_MV + 2] = c[2]; dst[SPJ_VL2] = c[3]; \
+              dst[SPJ_SMX] = c[4]; dst[SPJ_SMX + 1] = c[5]; dst[SPJ_SMX + 2] = c[6]; \
+              dst[SPJ_VLG] = c[7]; dst[SPJ_VL2G] = c[8]; dst[SPJ_VLS] = c[9]; dst[SPJ_VL2S] = c[10]; }
+        SPJ_SWEEP(11, SW_FILL_, SW_STORE_)
+#undef SW_FILL_
+#undef SW_STORE_
+#undef SPJ_SWEEP
+        WSYNC();
+        // ---- lanes = apertures: the columns that follow from the sums, and the half-mass targets [1] dark matter, [2] gas, [3] stars, [4] baryons
+        double tg[NHM] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (isp) {
+            const volatile double *a = g_W.pj[rank];
+            GAS double *prow = row + coloff + axis * PJ_NCOLS;
+            const double Mtot = ((a[SPJ_M0] + a[SPJ_M0 + 1]) + a[SPJ_M0 + 2]) + a[SPJ_M0 + 3];
+            prow[PJ_Mtot] = Mtot;
+            prow[PJ_Mgas] = a[SPJ_M0]; prow[PJ_Mdm] = a[SPJ_M0 + 1]; prow[PJ_Mstar] = a[SPJ_M0 + 2]; prow[PJ_Mbh] = a[SPJ_M0 + 3];
+            prow[PJ_Ngas] = a[SPJ_N0]; prow[PJ_Ndm] = a[SPJ_N0 + 1]; prow[PJ_Nstar] = a[SPJ_N0 + 2]; prow[PJ_Nbh] = a[SPJ_N0 + 3];
+            if (Mtot != 0.0) {
+                write_com(prow + PJ_com, a + SPJ_MX, Mtot, g_S.c, g_S.L);
+                for (int d = 0; d < 3; d++) prow[PJ_vcom + d] = a[SPJ_MV + d] / Mtot + g_S.shift[d];
+            }
+            const double Md = a[SPJ_M0 + 1], Mg = a[SPJ_M0], Ms = a[SPJ_M0 + 2];
+            if (Md != 0.0) {
+                // sqrt(sum w (v - <v>)^2), shifted form (projected_aperture_properties.py:946-957); a single particle has no dispersion
+                const double d1 = a[SPJ_VL] / Md, var = a[SPJ_VL2] / Md - d1 * d1;
+                prow[PJ_veldisp_dm] = (a[SPJ_N0 + 1] == 1.0) ? 0.0 : sqrt(var > 0.0 ? var : 0.0);
+            }
+            if (Ms != 0.0) write_com(prow + PJ_com_star, a + SPJ_SMX, Ms, g_S.c, g_S.L);
+            if (Mg != 0.0) {
+                const double d1 = a[SPJ_VLG] / Mg, var = a[SPJ_VL2G] / Mg - d1 * d1;
+                prow[PJ_veldisp_gas] = (a[SPJ_N0] == 1.0) ? 0.0 : sqrt(var > 0.0 ? var : 0.0);
+            }
+            if (Ms != 0.0) {
+                const double d1 = a[SPJ_VLS] / Ms, var = a[SPJ_VL2S] / Ms - d1 * d1;
+                prow[PJ_veldisp_star] = (a[SPJ_N0 + 2] == 1.0) ? 0.0 : sqrt(var > 0.0 ? var : 0.0);
+            }
+            tg[1] = 0.5 * Md; tg[2] = 0.5 * Mg; tg[3] = 0.5 * Ms; tg[4] = 0.5 * (Mg + Ms);
+        }
+        // ---- half-mass radii in projection: scan of the dark matter / gas / stellar mass in 2D-radius order
+        const int scan_n = rl(my_nc, __ffsll((long long)__ballot(isp && rank == __popcll(pm) - 1)) - 1);   // the largest aperture's members
+        double carryD = 0.0, carryG = 0.0, carryT = 0.0;
+#define SPJ_CLS(w, tt) (((w) == 1 && (tt) == 1) || ((w) == 2 && (tt) == 0) || ((w) == 3 && (tt) == 2) || ((w) == 4 && ((tt) == 0 || (tt) == 2)))
+#pragma unroll 1
+        for (int base = 0; base < scan_n; base += 64) {
+            const int p_ = base + LANE;
+            int t = -1;
+            double mm = 0.0, rp = 0.0;
+            if (p_ < scan_n) {
+                const int i = (int)g_W.pidx[p_];
+                t = g_W.flags[i] & FL_TYPE;
+                mm = CX(m)[i]; rp = g_W.cum[p_];
+            }
+            const double sD = wave_scan(t == 1 ? mm : 0.0, LANE) + carryD, sG = wave_scan(t == 0 ? mm : 0.0, LANE) + carryG,
+                         sT = wave_scan(t == 2 ? mm : 0.0, LANE) + carryT;
+            const double shD = dpp_f64<DPP_WAVE_SHR1>(sD), shG = dpp_f64<DPP_WAVE_SHR1>(sG), shT = dpp_f64<DPP_WAVE_SHR1>(sT);
+            const double pD = LANE == 0 ? carryD : shD, pG = LANE == 0 ? carryG : shG, pT = LANE == 0 ? carryT : shT;
+#pragma unroll
+            for (int w = 1; w < NHM; w++) {
+                unsigned long long open = __ballot(isp && tg[w] > 0.0 && my_nc > base);
+                while (open) {
+                    const int c2 = __ffsll((long long)open) - 1;
+                    open &= open - 1;
+                    const double tgt = rl64(tg[w], c2);
+                    const int n2 = rl(my_nc, c2);
+                    const double cv = w == 1 ? sD : (w == 2 ? sG : (w == 3 ? sT : sG + sT));
+                    const double pv = w == 1 ? pD : (w == 2 ? pG : (w == 3 ? pT : pG + pT));
+                    const unsigned long long hit = __ballot(t >= 0 && SPJ_CLS(w, t) && p_ < n2 && cv >= tgt);
+                    if (!hit) continue;
+                    const int owner = __ffsll((long long)hit) - 1;
+                    const double cv_o = rl64(cv, owner), r_o = rl64(rp, owner);
+                    double Wmin = rl64(pv, owner), rmin = 0.0;
+                    int j = base + owner - 1;   // previous member of the same class
+                    while (j >= 0) {
+                        const int tj = g_W.flags[g_W.pidx[j]] & FL_TYPE;
+                        if (SPJ_CLS(w, tj)) break;
+                        j--;
+                    }
+                    if (j < 0) Wmin = 0.0; else rmin = g_W.cum[j];
+                    const double h = (Wmin == cv_o) ? 0.5 * (rmin + r_o) : rmin + (tgt - Wmin) / (cv_o - Wmin) * (r_o - rmin);
+                    const int col = w == 1 ? PJ_HMR_dm : (w == 2 ? PJ_HMR_gas : (w == 3 ? PJ_HMR_star : PJ_HMR_baryon));
+                    if (LANE == c2) { row[coloff + axis * PJ_NCOLS + col] = h; tg[w] = 0.0; }   // found: the target is closed
+                }
+            }
+            carryD = rl64(sD, 63); carryG = rl64(sG, 63); carryT = rl64(sT, 63);
+        }
+#undef SPJ_CLS
+        WSYNC();
+    }
+}
+#endif   // SHYDRO
+
 // ======================= the kernel =======================================================================================
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWPE, 8)))
 SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int *todo, long long n_todo) {   // k_small128d / k_small512d: the variants show under their own names in a kernel trace
@@ -1318,7 +1741,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
     const unsigned long long flow_lanes = __ballot(LANE < ncalc && cd.kind == SOAP_CALC_SO_DENSITY && (cd.flags & SOAP_CALC_FLAG_DM_FLOW));
     if (LANE == 0) {
         g_W.L = P.boxsize; g_W.nu_density = P.nu_density; g_W.a = P.a; g_W.mpc = P.mpc; g_W.mpc20 = P.mpc20; g_W.G_eff = P.G_eff;
-        g_W.hydro = P.hydro; g_W.has_nu = P.has_nu;
+        g_W.hydro = P.hydro; g_W.has_nu = P.has_nu; g_W.mass_f32 = P.mass_f32;
 #if SGLOBAL
         g_W.cols = (GAS double *)(SNS > 512 ? P.small_cols2 : (SNS > 128 ? P.small_cols : P.small_cols0)) + (long long)blockIdx.x * (SC_NCOLS * SNS);
 #endif
@@ -1327,7 +1750,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
 #endif
     }
     WSYNC();
-    const double soft1 = P.soft[1];
+    const double soft[4] = {P.soft[0], P.soft[1], P.soft[2], P.soft[3]};   // (SHYDRO 0: only the dark matter's is used)
     const int dbg_stop = P.profile >= 100 ? P.profile - 100 : 0;   // diagnostics: SOAP_ENGINE_PROFILE=100+k ends every halo after phase k
     if (dbg_stop == 9) return;
     const double target_density = P.target_density, first_factor = P.first_factor;
@@ -1537,6 +1960,19 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                                     if (Rcur < Rap) res = RES_TOO_SMALL;   // aperture_properties.py:4140-4143
                                     else { st = 1; nin = count_r_le(n, Rap); Rv = Rap; }   // r <= R_ap (:310)
                                 } else if (copy_from >= 0) { st = 3; nin = copy_from; }
+#if SHYDRO
+                            } else if (cdf.kind == SOAP_CALC_PROJECTED) {
+                                // bound particles only: no search-radius check (projected_aperture_properties.py:1889-1891);
+                                // skip / copy rule as for exclusive spheres (:1827-1884)
+                                int copy_from = -1;
+                                bool skip = false;
+                                if (cdf.parent >= 0) {
+                                    const float enc = (float)encl;
+                                    if (cdf.prev_radius > (double)enc) { skip = true; if (filt) copy_from = cdf.parent; }
+                                }
+                                if (filt && !skip) { st = 1; Rv = cdf.radius; }
+                                else if (copy_from >= 0) { st = 3; nin = copy_from; }
+#endif
                             }
                         }
                         if (pending && !cached && res == RES_OK && (st == 1 || st == 3) && cdf.kind != SOAP_CALC_SO_MULTIPLE) {
@@ -1633,11 +2069,11 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                 double nfar, vs, rs;
                 const int m = small_family_order(fam && !isb, cs.n, &rank);
 #ifndef NO_MOM
-                small_moments(row, false, cd, coloff, cs, fam && !isb, rank, m, soft1, &nfar, &mo);
+                small_moments(row, false, cd, coloff, cs, fam && !isb, rank, m, soft, &nfar, &mo);
 #endif
 #ifndef NO_SCAN
                 if (dbg_stop != 4)
-                small_scan(row, false, cd, coloff, cs, fam && !isb, m, mo, soft1, nfar, nbound_total, &vs, &rs);
+                small_scan(row, false, cd, coloff, cs, fam && !isb, m, mo, soft, nfar, nbound_total, &vs, &rs);
 #endif
 #ifndef NO_FLOW
                 if (dbg_stop != 4 && dbg_stop != 5) {
@@ -1666,10 +2102,10 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                 double nfar, vs, rs;
                 const int m = small_family_order(fam && isb, cs.n, &rank);
 #ifndef NO_MOM
-                small_moments(row, true, cd, coloff, cs, fam && isb, rank, m, soft1, &nfar, &mo);
+                small_moments(row, true, cd, coloff, cs, fam && isb, rank, m, soft, &nfar, &mo);
 #endif
 #ifndef NO_SCAN
-                small_scan(row, true, cd, coloff, cs, fam && isb, m, mo, soft1, nfar, nbound_total, &vs, &rs);
+                small_scan(row, true, cd, coloff, cs, fam && isb, m, mo, soft, nfar, nbound_total, &vs, &rs);
                 if (rl(cs.state, 0) == 1) {
                     const double Mt0 = rl64(((mo.M[0] + mo.M[1]) + mo.M[2]) + mo.M[3], 0);
                     const double mv0[3] = {rl64(mo.MV[0], 0), rl64(mo.MV[1], 0), rl64(mo.MV[2], 0)};
@@ -1680,6 +2116,12 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
 #if SINERTIA
             __builtin_amdgcn_sched_barrier(0);
             small_inertia(row, cd.kind, cd.flags, coloff, cs.state, cs.n, cs.ev, cs.R, ncalc, nbound_total);
+#endif
+#if SHYDRO
+            __builtin_amdgcn_sched_barrier(0);
+            small_rotation(row, cd, coloff, cs, ncalc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rl(cs.state, 0) == 1) small_projected(row, cd, coloff, cs, ncalc, rl(cs.n, 0));
 #endif
             // exclusive spheres that repeat the next-smaller one (aperture_properties.py:4117-4123): copies of its columns
             {
@@ -1694,9 +2136,12 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
                         const GAS double *prow = row + rl(coloff, par);
                         GAS double *crow = row + rl(coloff, c2);
                         // (chains: a copy of a copy reads what the earlier iteration of this loop wrote)
-                        double v = 0.0;
-                        if (LANE < AP_NCOLS) v = prow[LANE];
-                        if (LANE < AP_NCOLS) crow[LANE] = v;
+                        const int ncopy = rl(cd.kind, c2) == SOAP_CALC_PROJECTED ? 3 * PJ_NCOLS : AP_NCOLS;
+                        for (int k0 = 0; k0 < ncopy; k0 += 64) {
+                            double v = 0.0;
+                            if (k0 + LANE < ncopy) v = prow[k0 + LANE];
+                            if (k0 + LANE < ncopy) crow[k0 + LANE] = v;
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }

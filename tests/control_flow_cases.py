@@ -12,6 +12,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "con
 # the same cases at a = 0.769 with quantities that carry units (comoving coordinates, physical densities ...): every
 # comoving <-> physical conversion is the reference's own (tests/golden/_shims_units)
 GOLDEN_UNITS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "control_flow_units.npz")
+# the same cases at a = 1 with Velocities and Masses in float32, as SWIFT snapshots hold them (make_control_flow_golden.py --f32): the
+# reference casts the cumulative mass of the SO profile back to float32 (SO_properties.py:400-402) and sums in float32
+GOLDEN_F32 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "control_flow_f32.npz")
 
 # category filters (core/category_filter.py: limit on the summed particle numbers of the bound subhalo)
 FILTERS = {
@@ -68,8 +71,8 @@ def variations(dmo, skip_incl):
 class Golden:
     """Reader of the packed fixture."""
 
-    def __init__(self, units=False):
-        self.z = np.load(GOLDEN_UNITS if units else GOLDEN)
+    def __init__(self, units=False, f32=False):
+        self.z = np.load(GOLDEN_F32 if f32 else (GOLDEN_UNITS if units else GOLDEN))
 
     def scalars(self):
         return {k.split("|")[1]: float(self.z[k]) for k in self.z.files if k.startswith("scalars|")}

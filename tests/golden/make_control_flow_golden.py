@@ -65,6 +65,10 @@ class PlainSharedArray:
 
 
 UNITS_MODE = "--units" in sys.argv   # second fixture: a = 0.769..., quantities carry units (tests/golden/_shims_units)
+# third fixture (`--f32`): the same boxes with Velocities and Masses in float32, as SWIFT snapshots hold them (Coordinates stay float64:
+# tests/dummy_halo_generator.py:806-811) -- the reference then casts the cumulative mass of the SO profile back to float32
+# (SO_properties.py:400-402) and sums masses and velocities in float32; a = 1, unit-less stand-in (tests/golden/control_flow_f32.npz)
+F32_MODE = "--f32" in sys.argv
 
 # units of the snapshot datasets and of the halo table, as swift_cells.py / halo_centres.py hand them over
 LEN_C = "snap_length*a"   # comoving length
@@ -272,6 +276,9 @@ def main():
     sc, data_t, halos_t = make_chunk(24000, 14, seed=78, scalars=sc0, hydro=True, satellite_fraction=0.15, read_radius_factor=8.0,
                                      nmin=40)
     boxes["hydro"] = to_numpy(data_t, halos_t)
+    if F32_MODE:
+        boxes = {bname: ({pt: {k: (v.astype(np.float32) if k in ("Velocities", "Masses") else v) for k, v in d.items()} for pt, d in bdata.items()}, bhalos)
+                 for bname, (bdata, bhalos) in boxes.items()}
     for bname, (bdata, bhalos) in boxes.items():
         for pt, d in bdata.items():
             for k, v in d.items():
@@ -379,7 +386,7 @@ def main():
             out[f"{tag}|values"] = np.concatenate(vals)
             out[f"{tag}|float32"] = np.array([np.asarray(result[k][0]).dtype == np.float32 for k in keys])
     out["scalars|a"] = np.array(A_EXP)
-    np.savez_compressed(os.path.join(HERE, "control_flow_units.npz" if UNITS_MODE else "control_flow.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "control_flow_units.npz" if UNITS_MODE else ("control_flow_f32.npz" if F32_MODE else "control_flow.npz")), **out)
     print("control-flow golden vectors written:", len(out), "arrays")
 
 

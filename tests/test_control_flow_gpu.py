@@ -39,13 +39,23 @@ def _scalars(g):
     return sc
 
 
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("vname", list(cases.VARIANTS))
+def test_engine_follows_the_reference_with_float32_velocities_and_masses(built_library, vname, resident):
+    """The float32 family (tests/golden/control_flow_f32.npz, `make_control_flow_golden.py --f32`): Velocities and Masses go through the C
+    ABI as float32 (`value_bytes` = 4), the engine mirrors the reference's cast of the cumulative mass of the SO profile back to float32
+    (SO_properties.py:400-402).  Attempts, radius rounds, verdicts, radii handed back, particle counts of every selection and the SO
+    radii as stored: exactly the reference's; the other values to the rounding of the reference's own float32 sums."""
+    test_engine_follows_the_reference_scheduler_and_classes(built_library, vname, resident, False, f32=True)
+
+
 @pytest.mark.parametrize("units", [False, True])
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("vname", list(cases.VARIANTS))
-def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname, resident, units):
+def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname, resident, units, f32=False):
     """units=True: the vectors made at a = 0.769 with unit-carrying quantities (tests/golden/_shims_units): the reference's
     own comoving <-> physical conversions and powers of a in every stored value."""
-    g = cases.Golden(units=units)
+    g = cases.Golden(units=units, f32=f32)
     bname, dmo, strict, skip_incl = cases.VARIANTS[vname]
     data, halos = g.box(bname)
     sc = _scalars(g)
@@ -129,7 +139,17 @@ def test_engine_follows_the_reference_scheduler_and_classes(built_library, vname
                 scale = 1.0
             if "AngularMomentum" in full or "InertiaTensor" in full or "VelocityDispersionMatrix" in full:
                 tol = 2e-6   # sums of signed terms (angular momenta of random velocities, off-diagonal elements)
+            if f32:
+                # the reference sums float32 masses, mass fractions and velocities in float32 (NumPy's pairwise order), the engine in
+                # float64: values agree to the rounding of THOSE sums.  What decides selections is exact: the SO radius as stored ...
+                if full.endswith("/SORadius"):
+                    np.testing.assert_array_equal(got, want, err_msg=f"{vname} halo {i} {full}")
+                tol = max(tol, 2e-5)
+                if "DiscToTotal" in full:
+                    tol = 1e-3   # (a member whose L_i changes sign with the rounding of the centre-of-mass velocity moves its whole mass)
+                if "MassFlowRate" in full or "AngularMomentum" in full or "KappaCorot" in full:
+                    tol = 2e-4
             err = np.abs(got.astype(float) - want.astype(float))
             assert np.all(err <= tol * np.maximum(np.abs(want.astype(float)), scale)), (vname, i, full, got, want)
-    assert n_values > 2000 and n_exact >= 0.97 * n_values, (n_exact, n_values)
+    assert n_values > 2000 and n_exact >= (0.3 if f32 else 0.97) * n_values, (n_exact, n_values)
     engine.close()

@@ -320,9 +320,19 @@ def _oracle_halo_prop_list(g, vname):
     return u, chp.build_halo_prop_list(None, None, so_vars, ap_vars, classes=classes, projected_vars=pj_vars)
 
 
+@pytest.mark.parametrize("vname", list(cases.VARIANTS))
+def test_process_single_halo_and_calculate_match_reference_with_float32_velocities_and_masses(vname):
+    """The same cases with Velocities and Masses in float32, as SWIFT snapshots hold them (tests/golden/control_flow_f32.npz,
+    `make_control_flow_golden.py --f32`): the reference casts the cumulative mass of the SO profile back to float32
+    (SO_properties.py:400-402), sums masses in float32 and lets NumPy's promotion rules decide the rest; the oracle is NumPy on the same
+    arrays and reproduces every attempt and every stored value bit for bit (found by these vectors: the baryon mass of the aperture and
+    subhalo classes is Mgas + Mstar, aperture_properties.py:535-539, not one sum over both)."""
+    test_process_single_halo_and_calculate_match_reference(vname, False, f32=True)
+
+
 @pytest.mark.parametrize("units", [False, True])
 @pytest.mark.parametrize("vname", list(cases.VARIANTS))
-def test_process_single_halo_and_calculate_match_reference(vname, units):
+def test_process_single_halo_and_calculate_match_reference(vname, units, f32=False):
     """Every attempt of every halo: the number of x1.2 loops, the verdict (done / read a larger region) and the search radius
     handed back; for finished halos every property the reference stored, as stored (float32 / uint32 / float64).
     units=True: the vectors made at a = 0.769 with unit-carrying quantities -- comoving coordinates, physical densities,
@@ -332,7 +342,7 @@ def test_process_single_halo_and_calculate_match_reference(vname, units):
 
     from soap_amd.property_table import full_property_list
 
-    g = cases.Golden(units=units)
+    g = cases.Golden(units=units, f32=f32)
     a_exp = g.scalars().get("a", 1.0)
     with open(os.path.join(os.path.dirname(__file__), "golden", "property_rows.json")) as f:
         ref_rows = json.load(f)

@@ -368,8 +368,9 @@ def test_per_halo_calculate_protocol(built_library):
 def test_device_resident_float32_inputs(built_library):
     """Real snapshots hold Velocities/Masses in float32 and the chunk may already live in HBM: float32 POINTERS go
     through the C ABI (`value_bytes` = 4 of soap_engine_stage_particles, widened on the device by the placement
-    pass), as device tensors and as host arrays, and give exactly the table of the same values passed as host
-    float64 arrays.  A float32 mass array beside float64 velocities is widened on the way in (one width per call)."""
+    pass), as device tensors and as host arrays, and give one table; the same values passed as host float64 arrays give the float64
+    semantics of the reference (no cast of the cumulative mass).  A float32 mass array beside float64 velocities is widened on the way
+    in (one width per call: the reference would concatenate such a chunk to float64 too)."""
     import torch
 
     from soap_amd import engine as engine_mod
@@ -413,7 +414,14 @@ def test_device_resident_float32_inputs(built_library):
     assert widths == [4, 4, 8]
     for o in (o2, o3, o4):
         assert np.array_equal(o1[4]["status"], o[4]["status"])
-        assert np.array_equal(o1[4]["table"], o[4]["table"])
+    # 8-byte values at the boundary: the table of the float64 arrays, bit for bit; 4-byte values, from the device or from the host: one
+    # table, bit for bit -- and the SO mass profile then goes through the reference's float32 casts of the cumulative mass
+    # (SO_properties.py:400-402; pinned by tests/golden/control_flow_f32.npz in tests/test_control_flow_gpu.py), so an SO radius may be the
+    # neighbouring float32 of the float64 run's and what hangs on it moves by that much
+    assert np.array_equal(o1[4]["table"], o4[4]["table"])
+    assert np.array_equal(o2[4]["table"], o3[4]["table"])
+    scale = np.maximum(np.abs(o1[4]["table"]).max(axis=0, keepdims=True), 1e-300)
+    assert np.all(np.abs(o2[4]["table"] - o1[4]["table"]) <= 2e-6 * np.abs(o1[4]["table"]) + 1e-7 * scale)
     for e in (e1, e2, e3, e4):
         e.close()
 
