@@ -1570,7 +1570,8 @@ static long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1
 int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_calcs,
                         double target_density) {
     static const bool trace = getenv("SOAP_ENGINE_TRACE") != nullptr;
-#define TRACE(msg) do { if (trace) { fprintf(stderr, "[soap_engine] %s\n", msg); fflush(stderr); } } while (0)
+    const auto t_trace0 = std::chrono::steady_clock::now();
+#define TRACE(msg) do { if (trace) { fprintf(stderr, "[soap_engine] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace0).count(), msg); fflush(stderr); } } while (0)
     if (!h) return fail(-1, "null handle");
     TRACE("run: begin");
     if (n_calcs < 1 || n_calcs > MAXCALC)
@@ -2110,6 +2111,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     };
     bool small_early = false;
     if (hybrid || giants) {
+        // (measured on a rank of 8 of the C3 box: with the pipeline's first build launches enqueued BEFORE these persistent kernels its
+        // set-up kernels no longer wait 0.8 ms for a free CU, but the histogram and gather passes of the build then do -- the verdicts
+        // of the first iteration arrive at the same moment either way)
         int rc = launch_single(early, h->ev_p[0], false);
         if (rc) return rc;
         // ... and the small-halo kernels with them: launched after the pipeline's iterations (whose host loop waits for every
@@ -2264,6 +2268,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipMemcpyAsync(d_cap, capv.data(), n * 4, hipMemcpyHostToDevice, st));
             if (iter == 0) HIPCHECK(hipMemcpyAsync(d_rbuild, rbuild.data(), n * 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, st, h->d_hdr, (long long)n, d_off, d_cap, (const double *)d_rbuild);
+            TRACE("pipeline: records initialised");
             // stage 1: small halos one thread group each; large halos (everything beyond the wavefront class) with
             // several workgroups per halo (k_g* kernels), on the stream of the 1024-thread class
             HIPCHECK(hipEventRecord(h->ev_p[1], st));
@@ -2344,6 +2349,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipEventRecord(C.pdone[0], cs));
                 HIPCHECK(hipEventRecord(C.done, cs));
                 HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
+                TRACE("pipeline: tile-parallel build launched");
                 if (C.pms[0] == 0.0) C.pms[0] = -1.0;
                 h->n_gbuild += (long long)L;
                 iter_tiles = (long long)tile_li.size();
@@ -2375,7 +2381,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->ev_p[3], st));
             HIPCHECK(hipMemcpyAsync(state.data(), d_state, n * 4, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(rbuild.data(), d_rbuild, n * 8, hipMemcpyDeviceToHost, st));
+            TRACE("pipeline: radius loop launched, waiting for the verdicts");
             HIPCHECK(hipStreamSynchronize(st));
+            TRACE("pipeline: verdicts read");
             {
                 hipError_t le = hipGetLastError();
                 if (le != hipSuccess) return fail(-101, std::string("pipeline: ") + hipGetErrorString(le));
