@@ -424,6 +424,7 @@ void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev are
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
                         const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
 void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart);
+int soap_team_max_groups();
 void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int groups, int split,
                       long long ntiles, long long ngblocks, long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
                       const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan);
@@ -892,6 +893,7 @@ struct soap_engine {
     double ms_host_pre = 0, ms_host_setup = 0, ms_host_classify = 0, ms_host_total = 0;   // wall clock inside run()
     unsigned *d_queue = nullptr;
     RunParams *d_params = nullptr;
+    RunParams *d_params_small = nullptr;  // the small-halo kernels' own copy (hand-over list, streamed-column buffers): uploaded after the large classes, which read d_params, have been launched
     RunParams *d_params_pipe = nullptr;   // the pipeline's own copy: its iterations rewrite hdr / tile tables while class and small-halo kernels of the same run read d_params
     unsigned long long *d_phase = nullptr;
     unsigned long long phase[32] = {};
@@ -945,6 +947,8 @@ struct soap_engine {
     // temporaries released -- by the next call that needs the mesh (finish_stage)
     bool stage_pending = false;
     int stage_pending_slot = -1;
+    int stage_error = 0;           // a deferred staging call failed and a call that cannot report it (soap_engine_kernel_ms) completed it: the next call that can does
+    std::string stage_error_msg;
     std::vector<std::pair<void *, size_t>> stage_scratch;
     // team run (k_team): its own stream (highest priority: launched first, resident from the start), control block, clocks
     hipStream_t team_stream = nullptr;
@@ -1102,6 +1106,7 @@ static int32_t create_resources(soap_engine *h) {
     HIPCHECK(hipMalloc((void **)&h->d_teamctl, sizeof(TeamCtl)));
     HIPCHECK(hipMalloc((void **)&h->d_params, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_params_pipe, sizeof(RunParams)));
+    HIPCHECK(hipMalloc((void **)&h->d_params_small, sizeof(RunParams)));
     HIPCHECK(hipMalloc((void **)&h->d_phase, 32 * sizeof(unsigned long long)));
     for (int k = 0; k < 6; k++) HIPCHECK(hipEventCreate(&h->ev_p[k]));
     return 0;
@@ -1124,6 +1129,11 @@ static void free_halos(soap_engine *h) {
 
 // completes a staging call that returned early (on_device = 2): what stage_type does at its end otherwise
 static int32_t finish_stage(soap_engine *h) {
+    if (h->stage_error) {   // (sticky until reported: the type's mesh was released, a run would silently go on without it)
+        const int e = h->stage_error;
+        h->stage_error = 0;
+        return fail(e, h->stage_error_msg);
+    }
     if (!h->stage_pending) return 0;
     h->stage_pending = false;
     const hipError_t se = hipStreamSynchronize(h->stream);
@@ -1132,7 +1142,8 @@ static int32_t finish_stage(soap_engine *h) {
     h->stage_scratch.clear();
     if (se != hipSuccess || le != hipSuccess) {
         if (h->stage_pending_slot >= 0) h->t[h->stage_pending_slot].release(h->pool);   // never a half-built mesh
-        return fail(-101, std::string("mesh build: ") + hipGetErrorString(se != hipSuccess ? se : le));
+        h->stage_error_msg = std::string("mesh build: ") + hipGetErrorString(se != hipSuccess ? se : le);
+        return fail(-101, h->stage_error_msg);
     }
     float ms1 = 0, ms2 = 0;
     (void)hipEventElapsedTime(&ms1, h->ev0, h->ev1);
@@ -1188,6 +1199,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_params_pipe) (void)hipFree(h->d_params_pipe);
+    if (h->d_params_small) (void)hipFree(h->d_params_small);
     if (h->d_phase) (void)hipFree(h->d_phase);
     if (h->d_hdr) (void)hipFree(h->d_hdr);
     if (h->d_gb) (void)hipFree(h->d_gb);
@@ -1574,6 +1586,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
 #define TRACE(msg) do { if (trace) { fprintf(stderr, "[soap_engine] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace0).count(), msg); fflush(stderr); } } while (0)
     if (!h) return fail(-1, "null handle");
     TRACE("run: begin");
+    // a staging call that returned with its placement pass in flight is completed FIRST, whatever this call goes on to return: the
+    // caller drops its references to the staged arrays when `run` comes back
+    (void)hipSetDevice(h->cfg.device);
+    { const int32_t frc = finish_stage(h); if (frc) return frc; }
     if (n_calcs < 1 || n_calcs > MAXCALC)
         return fail(-2, "number of calculations must be in [1,64]: one lane of a wavefront and one bit of the done mask each; split a "
                         "longer list into several runs, each starting with the bound subhalo");
@@ -1581,7 +1597,6 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (calcs[0].kind != SOAP_CALC_SUBHALO)
         return fail(-4, "the first calculation must be the bound subhalo (compute_halo_properties.py:232-247)");
     HIPCHECK(hipSetDevice(h->cfg.device));
-    { const int32_t frc = finish_stage(h); if (frc) return frc; }   // (a staging call that returned with its placement pass in flight)
     std::vector<int> coloff(n_calcs);
     long long ncols = 0;
     bool want_inertia = false, want_property_radius = false;
@@ -1986,7 +2001,6 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         P.small_esc = h->d_small_esc;
         HIPCHECK(hipMemsetAsync(h->d_small_esc, 0, sizeof(int), st));
-        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
     if (!todo_small[1].empty() || !todo_small[2].empty() || (!todo_small[0].empty() && soap_small_global_128d())) {
         // the streamed columns of the 512- and 1024-entry variants: a slice per persistent wave, one region per variant
@@ -2004,8 +2018,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         P.small_cols = h->d_small_cols;
         P.small_cols2 = need2 ? (double *)((char *)h->d_small_cols + need1) : nullptr;
         P.small_cols0 = need0 ? (double *)((char *)h->d_small_cols + need1 + need2) : nullptr;
-        HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     }
+    // the small-halo kernels read their own parameter block: the thread-group classes launched above are reading d_params by now, which
+    // is not written again in this run
+    if (!todo_small[0].empty() || !todo_small[1].empty() || !todo_small[2].empty())
+        HIPCHECK(hipMemcpyAsync(h->d_params_small, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
     TRACE("run: classified");
     const auto t_host2 = std::chrono::steady_clock::now();
     h->ms_host_setup = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
@@ -2038,14 +2055,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         C.nh += nt;
         const int ng = (int)std::min<long long>(groups_small[v], nt);
         if (small_hydro) {    // chunks with gas / stars / black holes
-            if (v == 0) soap_launch_small_128h(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-            else soap_launch_small_512h(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+            if (v == 0) soap_launch_small_128h(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+            else soap_launch_small_512h(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
         } else if (want_inertia) {   // the variants with the inertia tensor pass (more LDS per wave: fewer waves per CU)
-            if (v == 0) soap_launch_small_128i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-            else soap_launch_small_512i(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-        } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-        else if (v == 1) soap_launch_small_512d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
-        else soap_launch_small_1024d(ng, cs, h->d_params, C.d_queue, (const int *)C.d_todo, nt);
+            if (v == 0) soap_launch_small_128i(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+            else soap_launch_small_512i(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+        } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+        else if (v == 1) soap_launch_small_512d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+        else soap_launch_small_1024d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
@@ -2103,6 +2120,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
         const int nwg = (int)std::min<long long>(groups[0], (long long)(todo_small[0].size() + todo_small[1].size() + todo_small[2].size()));
         if (C.nh == 0) HIPCHECK(hipEventRecord(C.start, cs));   // (no launch of the class' own in this run: its clock starts here)
+        // (the same halos on 256-thread groups -- 512 or 1024 of them on this class' slab -- take 7.5 ms instead of 3.9: measured, round 5)
         if (!want_inertia) (narrow64 ? soap_launch_halo_64n32 : soap_launch_halo_64n)(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
         else (narrow64 ? soap_launch_halo_64i32 : soap_launch_halo_64i)(nwg, cs, h->d_params, C.slab, C.d_queue, (const int *)(h->d_small_esc + 1), -1);
         HIPCHECK(hipEventRecord(C.done, cs));
@@ -2487,6 +2505,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         int T = 128;
         { const char *e = getenv("SOAP_ENGINE_TEAMS"); if (e) T = atoi(e); }
         T = std::max(1, std::min(T, 256));
+        // every group of the team spins at the team barrier until all have arrived: never more groups than can be resident together
+        // (the kernel's LDS allows one per CU; a partitioned device has fewer CUs), less a margin for the persistent groups of the
+        // other classes that may hold a CU when the team starts
+        { const int fit = soap_team_max_groups(); if (fit > 0) T = std::max(1, std::min(T, fit - fit / 8)); }
         if (h->hdr_bytes < n * sizeof(HaloHdr)) {
             if (h->d_hdr) (void)hipFree(h->d_hdr);
             h->d_hdr = nullptr;
@@ -2916,7 +2938,12 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "halo_team")) return h->ms_team;
     if (!strcmp(name, "n_passes")) return (double)h->n_passes;   // launches of the single-kernel path (more than one: slab overflows)
     if (!strcmp(name, "mesh") || !strcmp(name, "reorder")) {
-        (void)finish_stage(const_cast<soap_engine *>(h));   // (the events of a staging call still in flight)
+        // (the events of a staging call still in flight.  This call cannot report a failure of that call: it is kept in the handle and the
+        // next soap_engine_run / stage_* / membership returns it)
+        soap_engine *hm = const_cast<soap_engine *>(h);
+        (void)hipSetDevice(hm->cfg.device);
+        const int32_t frc = finish_stage(hm);
+        if (frc) hm->stage_error = frc;
         return !strcmp(name, "mesh") ? h->ms_mesh : h->ms_reorder;
     }
     return -1.0;

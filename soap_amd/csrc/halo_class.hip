@@ -107,6 +107,14 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
     hipLaunchKernelGGL(k_gpost, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
+// workgroups of the team kernel that can be resident on the device at the same time (its groups meet at a spinning barrier)
+extern "C" int soap_team_max_groups() {
+    int per_cu = 0, dev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_team, GRP, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return per_cu * prop.multiProcessorCount;
+}
 // records of the large halos of a team run (k_ginit), then the team kernel: T teams of K workgroups, one persistent launch
 extern "C" void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int groups, int split,
                                  long long ntiles, long long ngblocks, long long nselparts,
