@@ -26,6 +26,14 @@
 #include "engine_common.h"
 
 static thread_local std::string g_err;
+// The switches INTEGRATION.md lists are read with getenv() on every run.  Everything else is an EXPERIMENT knob -- group counts, cost
+// models, launch orders, variants that were measured and lost -- and is honoured only by a library built with
+// -DSOAP_EXPERIMENTS (SOAP_BUILD_EXPERIMENTS=1 for __graft_entry__.build(), scripts/build_variant.sh): the product has one path per class.
+#ifdef SOAP_EXPERIMENTS
+static const char *expt_env(const char *name) { return getenv(name); }
+#else
+static const char *expt_env(const char *) { return nullptr; }
+#endif
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHECK(x)                                                                        \
     do {                                                                                   \
@@ -413,7 +421,6 @@ SOAP_DECL_LAUNCH(soap_launch_halo_64s); SOAP_DECL_LAUNCH(soap_launch_halo_256s);
 void soap_launch_small_128d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 int soap_small_global_128d();
 void soap_launch_small_512d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
-void soap_launch_small_1024d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_128i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 void soap_launch_small_512i(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 // the variants for chunks with gas / stars / black holes (per-type moments, five half-mass classes, rotation, projected apertures)
@@ -424,10 +431,14 @@ void soap_launch_gbuild(hipStream_t stream, const RunParams *params, SlabDev are
                         long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock,
                         const int *ngblock, const int *first_sel, const int *nsel, const int *bin_first, const int *nbin);
 void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart);
+#ifdef SOAP_EXPERIMENTS
+void soap_launch_small_1024d(int groups, hipStream_t stream, const RunParams *params, unsigned *queue, const int *todo, long long n_todo);
 int soap_team_max_groups();
 void soap_launch_team(hipStream_t stream, const RunParams *params, SlabDev arena, TeamCtl *ctl, long long nlarge, int groups, int split,
                       long long ntiles, long long ngblocks, long long nselparts, const int *rows, const int *first_tile, const int *ntile, const int *first_gblock, const int *ngblock,
                       const int *first_sel, const int *nsel, const int *bin_first, const int *nbin, double *bpart, double *bscan);
+#endif
+
 }
 
 // team run: one word per large halo for the host (the state its team left it in)
@@ -1072,11 +1083,11 @@ static int32_t create_resources(soap_engine *h) {
     // different priority are not.  Giants (class 2) first: they are the tail.
     int prio_least = 0, prio_greatest = 0;
     HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    h->own_streams = (prio_least - prio_greatest >= 2) && !getenv("SOAP_ENGINE_TWO_STREAMS");
+    h->own_streams = (prio_least - prio_greatest >= 2) && !expt_env("SOAP_ENGINE_TWO_STREAMS");
     for (int k = 0; k < 3; k++) {
         if (h->own_streams) {
             int prio = k == 0 ? prio_least : (k == 1 ? prio_least - 1 : prio_greatest);
-            if (const char *e = getenv("SOAP_ENGINE_PRIO")) {   // diagnostic: three digits, rank of class 0 / 1 / 2 (0 = least)
+            if (const char *e = expt_env("SOAP_ENGINE_PRIO")) {   // diagnostic: three digits, rank of class 0 / 1 / 2 (0 = least)
                 const int r = e[k] - '0';
                 prio = r == 0 ? prio_least : (r == 1 ? prio_least - 1 : prio_greatest);
             }
@@ -1706,7 +1717,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     long long nb_small = 16384, nb_medium = 262144;
     if (h->t[0].n > 0 || h->t[2].n > 0) nb_medium = 131072;
     { const char *e = getenv("SOAP_ENGINE_NB_SMALL"); if (e) nb_small = atoll(e); }
-    { const char *e = getenv("SOAP_ENGINE_NB_MEDIUM"); if (e) nb_medium = atoll(e); }
+    { const char *e = expt_env("SOAP_ENGINE_NB_MEDIUM"); if (e) nb_medium = atoll(e); }
     // (twice the class limit: the radius loop may take a sphere a round or two further than the estimate saw, and a halo
     // that outgrows its slab is done again in the next class, in a pass of its own -- 10 ms on C3 for three seeds in four
     // when the 256-thread class had no headroom)
@@ -1717,9 +1728,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         caps[0] = c0; caps[1] = c0 * 8; caps[2] = c0 * 64;
         nb_small = c0 / 4; nb_medium = c0 * 2;
     }
-    { const char *e = getenv("SOAP_ENGINE_G0"); if (e) groups[0] = atoi(e); }
-    { const char *e = getenv("SOAP_ENGINE_G1"); if (e) groups[1] = atoi(e); }
-    { const char *e = getenv("SOAP_ENGINE_G2"); if (e) groups[2] = atoi(e); }
+    { const char *e = expt_env("SOAP_ENGINE_G0"); if (e) groups[0] = atoi(e); }
+    { const char *e = expt_env("SOAP_ENGINE_G1"); if (e) groups[1] = atoi(e); }
+    { const char *e = expt_env("SOAP_ENGINE_G2"); if (e) groups[2] = atoi(e); }
     if (h->cfg.n_workgroups > 0) { groups[0] = h->cfg.n_workgroups * 4; groups[1] = h->cfg.n_workgroups; groups[2] = std::max(1, h->cfg.n_workgroups / 4); }
     // never below 256 entries: stage B parks 3 values per calculation in two slab columns (finalize_moments)
     for (int k = 0; k < 3; k++) caps[k] = std::max(std::min(caps[k], cap_max), 256ll);
@@ -1753,7 +1764,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (pred) {
             const int pred_force = getenv("SOAP_ENGINE_PRED_FORCE") && atoi(getenv("SOAP_ENGINE_PRED_FORCE")) != 0;
             long long pred_always = nb_small;
-            { const char *e = getenv("SOAP_ENGINE_PRED_ALWAYS"); if (e) pred_always = atoll(e); }
+            { const char *e = expt_env("SOAP_ENGINE_PRED_ALWAYS"); if (e) pred_always = atoll(e); }
             hipLaunchKernelGGL(k_predict, dim3(gw), dim3(BLK), 0, st, (const RunParams *)h->d_params, h->d_first, d_est, pred_min, pred_margin, pred_force, pred_always);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(h->h_first.data(), h->d_first, (size_t)h->n_halo * 8, hipMemcpyDeviceToHost, st));
@@ -1779,11 +1790,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     for (long long i = 0; i < h->n_halo; i++) { const double e = (double)std::max<long long>(est[i], 0); run_W += e; run_est_max = std::max(run_est_max, e); }
     const double run_t_all = run_W / (P.hydro ? 0.6e10 : 1.2e10) + 1.0e-3;
     const double run_tau = std::max(0.75 * run_t_all, 2.0e-3);
-    const bool load_classes = h->cfg.slab_capacity <= 0 && !getenv("SOAP_ENGINE_NB_SMALL") && !getenv("SOAP_ENGINE_NB_MEDIUM") &&
-                              !(getenv("SOAP_ENGINE_LOAD_CLASSES") && atoi(getenv("SOAP_ENGINE_LOAD_CLASSES")) == 0);
+    const bool load_classes = h->cfg.slab_capacity <= 0 && !getenv("SOAP_ENGINE_NB_SMALL") && !expt_env("SOAP_ENGINE_NB_MEDIUM") &&
+                              !(expt_env("SOAP_ENGINE_LOAD_CLASSES") && atoi(expt_env("SOAP_ENGINE_LOAD_CLASSES")) == 0);
     if (load_classes) {
         nb_small = std::min<long long>(nb_small, std::max<long long>(2048, (long long)(run_tau / 4.0e-7)));
-        const double medium_cost = getenv("SOAP_ENGINE_MEDIUM_COST") ? atof(getenv("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
+        const double medium_cost = expt_env("SOAP_ENGINE_MEDIUM_COST") ? atof(expt_env("SOAP_ENGINE_MEDIUM_COST")) : 6.0e-8;   // s per candidate, 256 threads
         nb_medium = std::min<long long>(nb_medium, std::max<long long>(2 * nb_small, (long long)(run_tau / medium_cost)));
     }
     // ---- three-stage pipeline: build the sorted superset of every halo in its arena slice
@@ -1793,7 +1804,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // single-kernel path below, which also serves the runs with inertia tensors / neutrinos / the literal mode.
     // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
     // the wavefront class' unit with LDS tables for 32 calculations (eight groups per CU instead of seven) for the lists that fit
-    const bool narrow64 = n_calcs <= 32 && !(getenv("SOAP_ENGINE_NARROW64") && atoi(getenv("SOAP_ENGINE_NARROW64")) == 0);
+    const bool narrow64 = n_calcs <= 32 && !(expt_env("SOAP_ENGINE_NARROW64") && atoi(expt_env("SOAP_ENGINE_NARROW64")) == 0);
     auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
         // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
         // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
@@ -1854,7 +1865,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // persistent groups to drain -- seed 5 of the C3 box, largest halo 5.7e5 candidates: 32.7 ms with it through the
         // pipeline, 27.8 ms without)
         double giant_factor = 1.0 + 0.5 * std::min(1.0, std::max(0.0, (run_t_all - 10.0e-3) / 10.0e-3));
-        { const char *e = getenv("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
+        { const char *e = expt_env("SOAP_ENGINE_GIANT_FACTOR"); if (e) giant_factor = atof(e); }
         if (run_est_max * 3.8e-8 > giant_factor * run_tau && run_est_max > 2.1e5) nb_giant = nb_medium;
         const char *e = getenv("SOAP_ENGINE_NB_GIANT");
         if (e) nb_giant = atoll(e);
@@ -1869,7 +1880,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     int only_class = -1;   // SOAP_ENGINE_ONLY_CLASS=k: profile one class alone (other halos stay unprocessed)
     { const char *e = getenv("SOAP_ENGINE_ONLY_CLASS"); if (e) only_class = atoi(e); }
     bool early_big = !(pipeline && (pmode == 1 || pmode == 2 || pmode == 4)) && !(pipeline && pmode == 3 && run_est_max > (double)nb_giant) && only_class < 0 &&
-                     !(getenv("SOAP_ENGINE_EARLY_BIG") && atoi(getenv("SOAP_ENGINE_EARLY_BIG")) == 0);
+                     !(expt_env("SOAP_ENGINE_EARLY_BIG") && atoi(expt_env("SOAP_ENGINE_EARLY_BIG")) == 0);
     if (early_big) {
         std::vector<std::pair<long long, int>> big;
         for (long long i = 0; i < h->n_halo; i++) if (est[i] > nb_small) big.push_back({std::min<long long>(est[i], 0xffffffffLL), (int)i});
@@ -1947,7 +1958,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         }
         if (n_tensor_calcs > 16 || n_projected > SMALL_MAXPJ) small_ok = false;
         if (small_hydro && getenv("SOAP_ENGINE_SMALL_HYDRO") && atoi(getenv("SOAP_ENGINE_SMALL_HYDRO")) == 0) small_ok = false;
-        if (want_inertia && getenv("SOAP_ENGINE_SMALL_INERTIA") && atoi(getenv("SOAP_ENGINE_SMALL_INERTIA")) == 0) small_ok = false;
+        if (want_inertia && expt_env("SOAP_ENGINE_SMALL_INERTIA") && atoi(expt_env("SOAP_ENGINE_SMALL_INERTIA")) == 0) small_ok = false;
         // SOAP_ENGINE_SMALL: 0 off; 4 (default) EVERY halo of the wavefront class goes through the small-halo kernels -- the
         // 128-entry one where the bound-particle count says so, the 512-entry one otherwise -- and what does not fit is handed on
         // (C3: 17.5 ms of halo kernels against 20.3 with the larger halos on the wavefront class from the start: its 2048
@@ -1956,20 +1967,20 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         { const char *e = getenv("SOAP_ENGINE_SMALL"); if (e) small_mode = atoi(e); }
         if (small_ok && small_mode != 0) {
             double small_factor = 1.6;
-            { const char *e = getenv("SOAP_ENGINE_SMALL_FACTOR"); if (e) small_factor = atof(e); }
-            const bool use512 = !(getenv("SOAP_ENGINE_SMALL512") && atoi(getenv("SOAP_ENGINE_SMALL512")) == 0);
+            { const char *e = expt_env("SOAP_ENGINE_SMALL_FACTOR"); if (e) small_factor = atof(e); }
+            const bool use512 = !(expt_env("SOAP_ENGINE_SMALL512") && atoi(expt_env("SOAP_ENGINE_SMALL512")) == 0);
             // The 1024-entry variant (25 KB of LDS and 256 registers per wave) is built and tested but NOT used by default: on C3 it
             // takes 11 560 halos and halves the hand-overs (11 865 -> 6 404, clean-up launch 5.1 -> 3.7 ms), and the halo phase stays at
             // 18.3 - 18.7 ms (rank of 8: 7.3 / 6.0 / 8.0 ms either way) -- the phase ends with the 256-thread class, not with the
             // clean-up.  SOAP_ENGINE_SMALL1024=1 switches it on; it has no tensor pass.
-            const bool use1024 = !want_inertia && !small_hydro && getenv("SOAP_ENGINE_SMALL1024") && atoi(getenv("SOAP_ENGINE_SMALL1024")) != 0;
+            const bool use1024 = !want_inertia && !small_hydro && expt_env("SOAP_ENGINE_SMALL1024") && atoi(expt_env("SOAP_ENGINE_SMALL1024")) != 0;
             std::vector<int> rest;
             rest.reserve(todo[0].size());
             // A halo that is certain to outgrow the largest LDS slab in use is done by the wavefront class after the small-halo
             // kernels -- one wave per halo, 4e-7 s per candidate: the longest of them are the chains that clean-up launch ends with,
             // alone on the GPU.  Above nb_overflow candidates such a halo goes to the 256-thread class from the start instead.
             long long nb_overflow = 1ll << 62;
-            { const char *e = getenv("SOAP_ENGINE_NB_OVERFLOW"); if (e) nb_overflow = atoll(e); }
+            { const char *e = expt_env("SOAP_ENGINE_NB_OVERFLOW"); if (e) nb_overflow = atoll(e); }
             const double small_fit = (double)(use1024 ? small_ns[2] : (use512 ? small_ns[1] : small_ns[0]));
             std::vector<int> to_medium;
             for (int i : todo[0]) {
@@ -1978,7 +1989,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 int v = pred <= (double)small_ns[0] ? 0 : (pred <= (double)small_ns[1] && use512 ? 1 : (pred <= (double)small_ns[2] && use1024 ? 2 : -1));
                 if (small_mode == 2) v = 0;   // (test hooks: every halo of the class tries the smallest slab first / the 512-entry / the 1024-entry variant)
                 if (small_mode == 3) v = 1;
+#ifdef SOAP_EXPERIMENTS
                 if (small_mode == 5 && !want_inertia && !small_hydro) v = 2;
+#endif
                 if (small_mode == 4 && v < 0) v = use1024 ? 2 : 1;   // (every halo of the class through the small-halo kernels: what does not fit is handed on)
                 if (v >= 0) todo_small[v].push_back(i); else rest.push_back(i);
             }
@@ -2032,9 +2045,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (want_inertia) groups_small[0] = 256 * 8;   // (20 KB of LDS per wave with the tensor pass)
     if (small_hydro) groups_small[0] = groups_small[1] = 256 * 8;   // (256 registers per wave: two waves per SIMD)
     { const char *e = getenv("SOAP_ENGINE_GS"); if (e) { groups_small[0] = groups_small[1] = atoi(e); groups_small[2] = std::min(groups_small[2], atoi(e)); } }
-    { const char *e = getenv("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
+    { const char *e = expt_env("SOAP_ENGINE_GS512"); if (e) groups_small[1] = atoi(e); }
     // every persistent wave of the 512- / 1024-entry variants owns a slice of the streamed-column buffer: never more waves than slices
-    { const char *e = getenv("SOAP_ENGINE_GS128"); if (e) groups_small[0] = atoi(e); }
+    { const char *e = expt_env("SOAP_ENGINE_GS128"); if (e) groups_small[0] = atoi(e); }
     groups_small[0] = std::min(std::max(1, groups_small[0]), SMALL_MAXG128);
     groups_small[1] = std::min(std::max(1, groups_small[1]), SMALL_MAXG512);
     groups_small[2] = std::min(std::max(1, groups_small[2]), SMALL_MAXG1024);
@@ -2062,7 +2075,11 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             else soap_launch_small_512i(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
         } else if (v == 0) soap_launch_small_128d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
         else if (v == 1) soap_launch_small_512d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
-        else soap_launch_small_1024d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);
+#ifdef SOAP_EXPERIMENTS
+        else soap_launch_small_1024d(ng, cs, h->d_params_small, C.d_queue, (const int *)C.d_todo, nt);   // (measured, no gain: DESIGN.md 5.5, 5.13)
+#else
+        else return fail(-103, "the 1024-entry small-halo kernel is only in builds with -DSOAP_EXPERIMENTS");
+#endif
         HIPCHECK(hipEventRecord(C.done, cs));
         if (join) HIPCHECK(hipStreamWaitEvent(st, C.done, 0));
         return 0;
@@ -2084,7 +2101,12 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     const bool hybrid = pipeline && pmode == 1;
     // SOAP_ENGINE_PIPELINE=4: the large halos go to TEAMS of workgroups inside one persistent launch (k_team) instead of the
     // multi-launch pipeline; everything else stays on the single-kernel path
+#ifdef SOAP_EXPERIMENTS
     const bool teams = pipeline && pmode == 4;
+#else
+    const bool teams = false;   // (SOAP_ENGINE_PIPELINE=4, k_team: built, tested, slower than the launches -- only in builds with -DSOAP_EXPERIMENTS)
+    if (pipeline && pmode == 4) return fail(-103, "SOAP_ENGINE_PIPELINE=4 (teams) needs a library built with -DSOAP_EXPERIMENTS");
+#endif
     if (teams || early_big) pipeline = false;   // (early_big: no halo of this run is the pipeline's -- decided before the large classes were launched)
     bool giants = pipeline && pmode == 3;
     if (giants) {
@@ -2136,7 +2158,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         if (rc) return rc;
         // ... and the small-halo kernels with them: launched after the pipeline's iterations (whose host loop waits for every
         // iteration's verdicts) they and the clean-up launch behind them were a serial tail of ~2.4 ms on an eighth of the C3 box
-        const bool small_late = getenv("SOAP_ENGINE_SMALL_LATE") && atoi(getenv("SOAP_ENGINE_SMALL_LATE")) != 0;
+        const bool small_late = expt_env("SOAP_ENGINE_SMALL_LATE") && atoi(expt_env("SOAP_ENGINE_SMALL_LATE")) != 0;
         if (!small_late && only_class < 0) {
             for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev_p[0], false);
             if (!rc) rc = launch_cleanup(false);
@@ -2172,7 +2194,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         HIPCHECK(h->pool.alloc((void **)&d_rbuild, n * 8));
         P.hdr = h->d_hdr;
         P.rebuild_factor = giants ? 1.6 : 1.25;   // (stage A already extrapolates the enclosed density to the target; giants: every extra iteration is a round of launches for a handful of halos)
-        { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) P.rebuild_factor = atof(e); }
+        { const char *e = expt_env("SOAP_ENGINE_REBUILD_FACTOR"); if (e) P.rebuild_factor = atof(e); }
         P.g_coarse = getenv("SOAP_ENGINE_G_COARSE") != nullptr && atoi(getenv("SOAP_ENGINE_G_COARSE")) != 0;
         HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
         auto launch_stage = [&](int mode, std::vector<int> (&lists)[3], hipEvent_t after, bool join, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int alt = -1) -> int32_t {
@@ -2236,9 +2258,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // Iterations: every halo goes through build -> radius loop -> property passes; a halo whose loop ran past its
         // superset is built again, further out (twice the radius the loop had reached, the region that is resident
         // permitting), in the next iteration -- the arena is laid out afresh for the halos of each iteration.
-        { const char *e = getenv("SOAP_ENGINE_PIPE_ONLY_CLASS"); if (e) for (int k = 0; k < 3; k++) if (k != atoi(e)) todo[k].clear(); }   // diagnostics
+        { const char *e = expt_env("SOAP_ENGINE_PIPE_ONLY_CLASS"); if (e) for (int k = 0; k < 3; k++) if (k != atoi(e)) todo[k].clear(); }   // diagnostics
         for (int iter = 0; iter < 8; iter++) {
-            if (iter > 0 && getenv("SOAP_ENGINE_PIPE_ONE_ITER")) { for (int k = 0; k < 3; k++) todo[k].clear(); break; }   // diagnostics
+            if (iter > 0 && expt_env("SOAP_ENGINE_PIPE_ONE_ITER")) { for (int k = 0; k < 3; k++) todo[k].clear(); break; }   // diagnostics
             long long nrows = 0;
             for (int k = 0; k < 3; k++) nrows += (long long)todo[k].size();
             if (nrows == 0) break;
@@ -2292,7 +2314,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             HIPCHECK(hipEventRecord(h->ev_p[1], st));
             std::vector<int> small_lists[3], none;
             long long iter_tiles = 0;   // tiles of the large halos built in this iteration
-            bool gbuild = getenv("SOAP_ENGINE_GBUILD") == nullptr || atoi(getenv("SOAP_ENGINE_GBUILD")) != 0;
+            bool gbuild = expt_env("SOAP_ENGINE_GBUILD") == nullptr || atoi(expt_env("SOAP_ENGINE_GBUILD")) != 0;
             if (gbuild) small_lists[0] = todo[0];
             else for (int k = 0; k < 3; k++) small_lists[k] = todo[k];
             if (gbuild && (!todo[1].empty() || !todo[2].empty())) {
@@ -2313,7 +2335,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                     // (bins of ~30 entries on average: a bin may hold up to half a block, and the bins at the core of a concentrated halo --
                     // or across a massive satellite -- hold tens of times the average once the build radius has been doubled twice; with
                     // ~120 per bin two halos of the uncapped C3 box fell back to ONE 1024-thread group each, 15 ms at the end of the pass)
-                    const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
+                    const long long giant_bin = expt_env("SOAP_ENGINE_GIANT_BIN") ? atoll(expt_env("SOAP_ENGINE_GIANT_BIN")) : 64;
                     const int nbin = giant_sort ? (int)std::max<long long>(next_pow2(e / giant_bin), 64) : 0;
                     bin_first.push_back(giant_sort ? (int)nbins_total : -1); nbinv.push_back(nbin);
                     if (giant_sort) nbins_total += 2ll * nbin + 1 + ng + 1;
@@ -2434,13 +2456,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             // (projected apertures are a pass of the undivided halo: stage_b runs them with part == 0 only)
             bool any_projected = false;
             for (int c = 0; c < n_calcs; c++) any_projected = any_projected || calcs[c].kind == SOAP_CALC_PROJECTED;
-            const bool split = !P.hydro && !any_projected && (getenv("SOAP_ENGINE_SPLIT_PROPS") == nullptr || atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) != 0);
+            const bool split = !P.hydro && !any_projected && (expt_env("SOAP_ENGINE_SPLIT_PROPS") == nullptr || atoi(expt_env("SOAP_ENGINE_SPLIT_PROPS")) != 0);
             for (int k = 0; k < 3; k++)
                 for (int i : fin[k]) {
                     if (split && k > 0) { fin2[k].push_back(i | (1 << 29)); fin2[k].push_back(i | (2 << 29)); }
                     else fin2[k].push_back(i);
                 }
-            if (giants && getenv("SOAP_ENGINE_GIANT_PROPS_CLASS") && atoi(getenv("SOAP_ENGINE_GIANT_PROPS_CLASS")) == 1) {
+            if (giants && expt_env("SOAP_ENGINE_GIANT_PROPS_CLASS") && atoi(expt_env("SOAP_ENGINE_GIANT_PROPS_CLASS")) == 1) {
                 // experiment: the 256-thread variant of the property kernel (256 VGPRs, no spills in the sweeps)
                 fin2[1].insert(fin2[1].end(), fin2[2].begin(), fin2[2].end());
                 fin2[2].clear();
@@ -2508,7 +2530,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // every group of the team spins at the team barrier until all have arrived: never more groups than can be resident together
         // (the kernel's LDS allows one per CU; a partitioned device has fewer CUs), less a margin for the persistent groups of the
         // other classes that may hold a CU when the team starts
+#ifdef SOAP_EXPERIMENTS
         { const int fit = soap_team_max_groups(); if (fit > 0) T = std::max(1, std::min(T, fit - fit / 8)); }
+#endif
         if (h->hdr_bytes < n * sizeof(HaloHdr)) {
             if (h->d_hdr) (void)hipFree(h->d_hdr);
             h->d_hdr = nullptr;
@@ -2520,7 +2544,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         std::vector<int> rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, tile_li, gblock_li, sel_li, bin_first, nbinv;
         long long total = 0, nbins_total = 0;
         const long long giant_sort_limit = getenv("SOAP_ENGINE_GIANT_SORT") ? atoll(getenv("SOAP_ENGINE_GIANT_SORT")) : 300000;
-        const long long giant_bin = getenv("SOAP_ENGINE_GIANT_BIN") ? atoll(getenv("SOAP_ENGINE_GIANT_BIN")) : 64;
+        const long long giant_bin = expt_env("SOAP_ENGINE_GIANT_BIN") ? atoll(expt_env("SOAP_ENGINE_GIANT_BIN")) : 64;
         for (size_t li = 0; li < L; li++) {
             const int i = team_rows[li];
             // room for the sphere the guess reaches and for one rebuild further out (the team checks before it builds again)
@@ -2592,19 +2616,21 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         RunParams PT = P;
         PT.hdr = h->d_hdr; PT.gb = h->d_gb; PT.tile_li = dptr[5]; PT.gblock_li = dptr[6]; PT.sel_li = dptr[9]; PT.gbins = h->d_gbins;
         PT.rebuild_factor = 1.6;
-        { const char *e = getenv("SOAP_ENGINE_REBUILD_FACTOR"); if (e) PT.rebuild_factor = atof(e); }
+        { const char *e = expt_env("SOAP_ENGINE_REBUILD_FACTOR"); if (e) PT.rebuild_factor = atof(e); }
         PT.g_coarse = getenv("SOAP_ENGINE_G_COARSE") != nullptr && atoi(getenv("SOAP_ENGINE_G_COARSE")) != 0;
         HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &PT, sizeof(RunParams), hipMemcpyHostToDevice, ts));
         HIPCHECK(hipMemsetAsync(h->d_teamctl, 0, sizeof(TeamCtl), ts));
         hipLaunchKernelGGL(k_init_hdr, dim3((unsigned)std::min<size_t>((n + BLK - 1) / BLK, 2048)), dim3(BLK), 0, ts, h->d_hdr, (long long)n, d_toff, d_tcap, (const double *)d_trb);
         bool any_projected = false;
         for (int c = 0; c < n_calcs; c++) any_projected = any_projected || calcs[c].kind == SOAP_CALC_PROJECTED;
-        const int split = (!P.hydro && !any_projected && !(getenv("SOAP_ENGINE_SPLIT_PROPS") && atoi(getenv("SOAP_ENGINE_SPLIT_PROPS")) == 0)) ? 1 : 0;
+        const int split = (!P.hydro && !any_projected && !(expt_env("SOAP_ENGINE_SPLIT_PROPS") && atoi(expt_env("SOAP_ENGINE_SPLIT_PROPS")) == 0)) ? 1 : 0;
         const bool use_bpartials = getenv("SOAP_ENGINE_BPARTIALS") == nullptr || atoi(getenv("SOAP_ENGINE_BPARTIALS")) != 0;
         double *bpart = use_bpartials ? h->d_bpart[0] : nullptr;
         HIPCHECK(hipEventRecord(h->team_start, ts));
+#ifdef SOAP_EXPERIMENTS
         soap_launch_team(ts, h->d_params_pipe, h->arena, h->d_teamctl, (long long)L, T, split, (long long)tile_li.size(), (long long)gblock_li.size(), (long long)sel_li.size(),
                          dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[7], dptr[8], dptr[10], dptr[11], bpart, bpart ? bpart + ntiles_total * 2 * NACC : nullptr);
+#endif
         hipLaunchKernelGGL(k_team_states, dim3((unsigned)std::min<size_t>((L + BLK - 1) / BLK, 256)), dim3(BLK), 0, ts, (const HaloHdr *)h->d_hdr, (const int *)dptr[0], (long long)L, d_tstate);
         HIPCHECK(hipEventRecord(h->team_done, ts));
         HIPCHECK(hipGetLastError());
@@ -2642,7 +2668,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         {
             // the thread-group classes first, largest groups first: a 1024-thread group needs an empty CU, and the waves of the
             // small-halo class (three per SIMD fill its registers) would never leave one
-            const bool small_first = getenv("SOAP_ENGINE_SMALL_FIRST") && atoi(getenv("SOAP_ENGINE_SMALL_FIRST")) != 0;
+            const bool small_first = expt_env("SOAP_ENGINE_SMALL_FIRST") && atoi(expt_env("SOAP_ENGINE_SMALL_FIRST")) != 0;
             int rc = 0;
             const bool launch_small_now = !(small_early && pass == 0);   // (giants' mode: they started before the pipeline)
             if (small_first && launch_small_now) for (int v = 0; v < NSV && !rc; v++) rc = launch_small(v, todo_small[v], h->ev0, true);
@@ -2933,6 +2959,11 @@ double soap_engine_kernel_ms(const soap_engine *h, const char *name) {
     if (!strcmp(name, "n_gbuild")) return (double)h->n_gbuild;
     if (!strcmp(name, "n_single")) return (double)h->n_single;
     if (!strcmp(name, "n_predicted")) return (double)h->n_predicted;
+#ifdef SOAP_EXPERIMENTS
+    if (!strcmp(name, "experiments")) return 1.0;   // the library carries the experiment knobs and the measured-slower paths (teams, 1024-entry small-halo kernel)
+#else
+    if (!strcmp(name, "experiments")) return 0.0;
+#endif
     if (!strcmp(name, "n_team")) return (double)h->n_team;
     if (!strcmp(name, "n_team_failed")) return (double)h->n_team_failed;
     if (!strcmp(name, "halo_team")) return h->ms_team;

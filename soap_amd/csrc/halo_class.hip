@@ -107,6 +107,7 @@ extern "C" void soap_launch_gbuild(hipStream_t stream, const RunParams *params, 
     hipLaunchKernelGGL(k_gpost, dim3(gt), dim3(256), 0, stream, params, arena, ntiles);
     hipLaunchKernelGGL(k_gfinal, dim3(g64), dim3(64), 0, stream, params, arena, nlarge);
 }
+#ifdef SOAP_EXPERIMENTS
 // workgroups of the team kernel that can be resident on the device at the same time (its groups meet at a spinning barrier)
 extern "C" int soap_team_max_groups() {
     int per_cu = 0, dev = 0;
@@ -124,6 +125,7 @@ extern "C" void soap_launch_team(hipStream_t stream, const RunParams *params, Sl
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((nlarge + 63) / 64)), dim3(64), 0, stream, params, nlarge, rows, first_tile, ntile, first_gblock, ngblock, first_sel, nsel, bin_first, nbin);
     hipLaunchKernelGGL(k_team, dim3((unsigned)groups), dim3(GRP), 0, stream, params, arena, ctl, nlarge, 0, split, bpart, bscan, ntiles, ngblocks, nselparts);
 }
+#endif   // SOAP_EXPERIMENTS
 // tile sums for the property stage of the large halos whose radius loop has finished (k_bpartials)
 extern "C" void soap_launch_bpartials(hipStream_t stream, const RunParams *params, SlabDev arena, long long ntiles, double *bpart) {
     if (ntiles <= 0) return;

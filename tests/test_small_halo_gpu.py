@@ -80,11 +80,12 @@ def test_small_class_matches_the_oracle_and_the_general_path(built_library, monk
     assert n6 >= n2 and e6 < e2, (n2, n6, e2, e6)
     _same_selections(ha6, raw6, ha0, raw0)
     assert _close(t6, t0)
-    # ... and through the variant with 1024 slab entries
-    ha8, res8, raw8, t8, (n8, e8) = _run(engine, props, sc, halos_np, 5, monkeypatch)
-    assert n8 >= n6 and e8 <= e6, (n6, n8, e6, e8)
-    _same_selections(ha8, raw8, ha0, raw0)
-    assert _close(t8, t0)
+    # ... and through the variant with 1024 slab entries (measured, no gain: only in a library built with -DSOAP_EXPERIMENTS)
+    if engine.kernel_ms("experiments") == 1.0:
+        ha8, res8, raw8, t8, (n8, e8) = _run(engine, props, sc, halos_np, 5, monkeypatch)
+        assert n8 >= n6 and e8 <= e6, (n6, n8, e6, e8)
+        _same_selections(ha8, raw8, ha0, raw0)
+        assert _close(t8, t0)
     # the default: every halo of the wavefront class through the variant its bound-particle count suggests
     ha7, res7, raw7, t7, (n7, e7) = _run(engine, props, sc, halos_np, 4, monkeypatch)
     assert n7 >= n2, (n2, n7)
