@@ -2118,10 +2118,11 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
             small_inertia(row, cd.kind, cd.flags, coloff, cs.state, cs.n, cs.ev, cs.R, ncalc, nbound_total);
 #endif
 #if SHYDRO
+            // (diagnostics: SOAP_ENGINE_PROFILE=110 everything but these two passes, 111 with the rotation pass)
             __builtin_amdgcn_sched_barrier(0);
-            small_rotation(row, cd, coloff, cs, ncalc);
+            if (dbg_stop == 0 || dbg_stop == 11) small_rotation(row, cd, coloff, cs, ncalc);
             __builtin_amdgcn_sched_barrier(0);
-            if (rl(cs.state, 0) == 1) small_projected(row, cd, coloff, cs, ncalc, rl(cs.n, 0));
+            if (dbg_stop == 0 && rl(cs.state, 0) == 1) small_projected(row, cd, coloff, cs, ncalc, rl(cs.n, 0));
 #endif
             // exclusive spheres that repeat the next-smaller one (aperture_properties.py:4117-4123): copies of its columns
             {
