@@ -520,7 +520,7 @@ def main():
         # bench): only quoted when the workload is the one that was profiled
         traffic = None
         tnote = "no PMC profile of this workload committed"
-        for prof in ("round4", "round3", "round2", "round1"):
+        for prof in ("round5", "round4", "round3", "round2", "round1"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof, "final_c3_hbm_traffic.json")) as f:
                     pj = json.load(f)

@@ -46,6 +46,14 @@ for cfg in sys.argv[1:] or ["-"]:
             else:
                 scale = np.maximum(np.abs(ref[0]).max(axis=0, keepdims=True), 1e-300)
                 bad = np.abs(t - ref[0]) > 1e-11 * np.abs(ref[0]) + 1e-13 * scale
+                if bad.any() and os.environ.get("CHECK_COLUMNS") == "1":
+                    # which columns: (calculation, column within it, count, worst relative difference)
+                    ncols = [eng.desc_columns(hp.calc_desc(props, i)) for i, hp in enumerate(props)]
+                    offs = np.concatenate([[0], np.cumsum(ncols)])
+                    for j in np.flatnonzero(bad.any(axis=0))[:40]:
+                        c = int(np.searchsorted(offs, j, side="right") - 1)
+                        rel = np.abs(t[:, j] - ref[0][:, j]) / np.maximum(np.abs(ref[0][:, j]), 1e-300)
+                        print(f"   column {j}: calculation {c} ({type(props[c]).__name__}) + {j - offs[c]}: {int(bad[:, j].sum())} rows, worst rel {rel[bad[:, j]].max():.3g}", flush=True)
                 msg = f" | vs first: values differing {int(bad.sum())} status {int(np.sum(out[4]['status'] != ref[1]))} stats {int(np.sum(out[4]['stats'][:, [0, 1, 2, 4, 5]] != ref[2]))} radii {int(np.sum(ha['search_radius'] != ref[3]))}"
         print(f"{cfg:40s} {line} | {cnt} left {left}{msg}", flush=True)
         eng.close()

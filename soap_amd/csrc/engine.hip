@@ -925,6 +925,9 @@ struct soap_engine {
     } cls[3];
     Class small[NSV];   // the small-halo class (no slab: its halos live in LDS), by slab entries: 128 (all of it in LDS), 512 and 1024 (streamed columns in global memory)
     double *d_small_cols = nullptr;   // ... the latter's columns: seven per persistent wave
+    int *d_part_count = nullptr;      // large halos of chunks with gas / stars shared by two 1024-thread groups: groups that have finished, per row
+    size_t part_count_n = 0;
+    std::vector<int> split_rows;      // ... their task list (two entries per row)
     int *d_small_esc = nullptr;       // [0] count, then the rows the small-halo kernels hand on to the wavefront class
     size_t small_esc_count = 0;
     size_t small_cols_bytes = 0;
@@ -1203,6 +1206,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->d_first) (void)hipFree(h->d_first);
     if (h->d_small_cols) (void)hipFree(h->d_small_cols);
     if (h->d_small_esc) (void)hipFree(h->d_small_esc);
+    if (h->d_part_count) (void)hipFree(h->d_part_count);
     probe("small");
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_calcs) (void)hipFree(h->d_calcs);
@@ -1705,6 +1709,22 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     P.ncalc = n_calcs; P.ncols = ncols; P.table = h->d_table; P.queue = h->d_queue;
     P.calcs = h->d_calcs; P.coloff = h->d_coloff;
     P.phase = h->d_phase;
+    // Experiment (builds with -DSOAP_EXPERIMENTS, SOAP_ENGINE_SPLIT_LARGE=1): chunks with gas and stars, a halo of the 1024-thread class shared
+    // by TWO groups -- both build the sorted slab and run the radius loop (the same decisions to the bit), then one does the calculations
+    // over all particles, the other those over the bound particles and the projected apertures (stage_b's shares).  Same values; on the C5
+    // share the class ends at 11.3 instead of 15.2 ms and the phase stays at 15.4: the second build of 65 halos (7.4 of a halo's 15 ms) costs
+    // the 500 CU ms the other CUs were idle for.
+    bool split_large = false;
+    { const char *e = expt_env("SOAP_ENGINE_SPLIT_LARGE"); if (e) split_large = atoi(e) != 0 && P.hydro && !want_inertia && h->n_halo < (1ll << 29) && h->probe_row < 0 && !P.literal; }
+    if (split_large) {
+        if (h->part_count_n < (size_t)h->n_halo) {
+            if (h->d_part_count) (void)hipFree(h->d_part_count);
+            h->d_part_count = nullptr;
+            h->part_count_n = (size_t)h->n_halo + (size_t)h->n_halo / 4;
+            HIPCHECK(hipMalloc((void **)&h->d_part_count, h->part_count_n * sizeof(int)));
+        }
+        P.halo.part_count = h->d_part_count;
+    }
     HIPCHECK(hipMemsetAsync(h->d_phase, 0, 32 * sizeof(unsigned long long), st));
     HIPCHECK(hipMemcpyAsync(h->d_params, &P, sizeof(RunParams), hipMemcpyHostToDevice, st));
 
@@ -1805,6 +1825,13 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     // one launch of the single-kernel path per class on the class streams (no host synchronisation here)
     // the wavefront class' unit with LDS tables for 32 calculations (eight groups per CU instead of seven) for the lists that fit
     const bool narrow64 = n_calcs <= 32 && !(expt_env("SOAP_ENGINE_NARROW64") && atoi(expt_env("SOAP_ENGINE_NARROW64")) == 0);
+    // (shared halos: a group per task where the slabs fit in memory -- the tasks of a halo should start together -- with the same headroom
+    // of three radius rounds as below, here without giving up groups for it: 105 B per slab entry, at most 64 GB in all)
+    auto size_top_split = [&](long long n_tasks, long long need) {
+        if (!split_large || n_tasks == 0) return;
+        groups[2] = (int)std::max<long long>(groups[2], std::min<long long>(n_tasks, 256));
+        while (caps[2] < cap_max && caps[2] < 4 * need && 2.0 * (double)caps[2] * (double)groups[2] * 105.0 <= 64.0e9) caps[2] = std::min(caps[2] * 2, cap_max);
+    };
     auto launch_single = [&](std::vector<int> (&lists)[3], hipEvent_t after, bool join) -> int32_t {
         // submission order: the 1024-thread class (few, long halos) first.  Without three priority levels
         // the 1024-thread and wavefront classes share one stream and the 256-thread class takes the other
@@ -1815,7 +1842,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             soap_engine::Class &C = h->cls[k];
             hipStream_t cs = h->own_streams ? C.stream : ((k == 1) ? h->cls[0].stream : h->cls[2].stream);
             if (lists[k].empty()) continue;
-            const long long nt = (long long)lists[k].size();
+            const int *task_list = lists[k].data();
+            long long nt = (long long)lists[k].size();
+            if (k == 2 && split_large) {
+                // two tasks per row, side by side in the queue: bits 29-31 = the shares (PART_* of stage_b: 1 all particles, 2 | 4 bound particles + projected apertures)
+                h->split_rows.clear();
+                for (int i : lists[k]) { h->split_rows.push_back((int)((unsigned)i | (1u << 29))); h->split_rows.push_back((int)((unsigned)i | (6u << 29))); }
+                task_list = h->split_rows.data();
+                nt = (long long)h->split_rows.size();
+            }
             const int nwg = (int)std::min<long long>(groups[k], nt);
             int rc = alloc_slab(C, caps[k], groups[k]);
             if (rc) return rc;
@@ -1825,11 +1860,12 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 HIPCHECK(hipMalloc((void **)&C.d_todo, (size_t)C.todo_cap * 4));
             }
             HIPCHECK(hipStreamWaitEvent(cs, after, 0));
-            HIPCHECK(hipMemcpyAsync(C.d_todo, lists[k].data(), (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+            HIPCHECK(hipMemcpyAsync(C.d_todo, task_list, (size_t)nt * 4, hipMemcpyHostToDevice, cs));
+            if (k == 2 && split_large) HIPCHECK(hipMemsetAsync(h->d_part_count, 0, (size_t)h->n_halo * sizeof(int), cs));
             HIPCHECK(hipMemsetAsync(C.d_queue, 0, sizeof(unsigned), cs));
             const RunParams *dp = h->d_params;
             HIPCHECK(hipEventRecord(C.start, cs));
-            C.nh += nt;
+            C.nh += (long long)lists[k].size();
             if (!want_inertia) {
                 if (k == 0 && narrow64) soap_launch_halo_64n32(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
                 else if (k == 0) soap_launch_halo_64n(nwg, cs, dp, C.slab, C.d_queue, (const int *)C.d_todo, nt);
@@ -1888,9 +1924,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         for (auto &b : big) early[b.first <= nb_medium ? 1 : 2].push_back(b.second);
         {
             // (room in the largest class' slab for the largest sphere and three rounds more: see the single-kernel passes below)
-            long long need = 0, n_top = (long long)early[2].size();
+            long long need = 0, n_top = (long long)early[2].size() * (split_large ? 2 : 1);
             for (int i : early[2]) need = std::max(need, est[i]);
-            while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, 64))) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
+            size_top_split(n_top, need);
+            while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, split_large ? 256 : 64))) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
             while (caps[2] < cap_max && caps[2] < need + need / 4) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
         }
         HIPCHECK(hipEventRecord(h->ev_p[0], st));
@@ -2650,8 +2687,9 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
         // (the radius loop may take the sphere a few x1.2 rounds further, x1.7 in content each: room for three of them --
         // a halo that overflows is done again in a pass of its own, which doubles the time of the largest halo)
         long long n_top = 0;
-        for (int i : todo[2]) n_top++;
-        while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, 64))) {
+        for (int i : todo[2]) n_top += split_large ? 2 : 1;
+        size_top_split(n_top, need);
+        while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, split_large ? 256 : 64))) {
             caps[2] = std::min(caps[2] * 2, cap_max);
             groups[2] = std::max(1, groups[2] / 2);
         }

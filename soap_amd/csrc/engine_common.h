@@ -93,6 +93,7 @@ struct HaloDev {
     long long n_todo;
     const double *resident;   // optional: radius inside which the staged particles are complete (>= read_radius)
     const double *first_radius;   // optional: radius the first sorted superset of a halo should reach (k_predict; 0 = the default)
+    int *part_count;              // halos that several groups of the single-kernel path share (stage_b's shares): groups that have finished, per row (zeroed per run), or null
 };
 
 // Per-halo record of the three-stage pipeline (build -> radius loop -> property passes): what the stages hand to

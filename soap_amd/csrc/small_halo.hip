@@ -1446,14 +1446,23 @@ __device__ __forceinline__ void small_rotation(GAS double *row, const soap_calc_
             bound_only = kind == SOAP_CALC_APERTURE_EXCL;
         } else { cNg = SOC_Ngas; cNs = SOC_Nstar; cMg = SOC_Mgas; cMs = SOC_Mstar; cLg = SOC_Lgas; cLs = SOC_Lstar; cLb = SOC_Lbaryons; cKap = -1; cDt = SOC_DtoT; }
         GAS double *crow = row + rl(coloff, c2);
-        const double Mg = uni(crow[cMg]), Ms = uni(crow[cMs]);
+        // (everything this calculation reads of its row in ONE round trip: the loads are issued before the first value is looked at)
+        const double Mg_ = crow[cMg], Ms_ = crow[cMs], Ng_ = crow[cNg], Ns_ = crow[cNs];
+        double lv_[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int cl = q == 0 ? cLg : (q == 1 ? cLs : cLb);
+#pragma unroll
+            for (int d = 0; d < 3; d++) lv_[q][d] = (q == 2 && cKap < 0) ? 0.0 : crow[cl + d];
+        }
+        const double Mg = uni(Mg_), Ms = uni(Ms_), Ng = uni(Ng_), Ns = uni(Ns_);
         if (Mg == 0.0 && Ms == 0.0) continue;
         // centre-of-mass velocities (slab frame), unit vectors along L and |L| of gas, stars, baryons
         double vc[3][3], hh[3][3], ln[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            const int cl = q == 0 ? cLg : (q == 1 ? cLs : cLb);
-            const double lx = uni(crow[cl]), ly = uni(crow[cl + 1]), lz = uni(crow[cl + 2]);
+            if (q == 2 && cKap < 0) { ln[q] = 0.0; for (int d = 0; d < 3; d++) { hh[q][d] = 0.0; vc[q][d] = 0.0; } continue; }   // (no baryon pass without kappa_corot)
+            const double lx = uni(lv_[q][0]), ly = uni(lv_[q][1]), lz = uni(lv_[q][2]);
             const double nn = sqrt((lx * lx + ly * ly) + lz * lz);
             ln[q] = nn;
             hh[q][0] = nn > 0.0 ? lx / nn : 0.0; hh[q][1] = nn > 0.0 ? ly / nn : 0.0; hh[q][2] = nn > 0.0 ? lz / nn : 0.0;
@@ -1473,6 +1482,17 @@ __device__ __forceinline__ void small_rotation(GAS double *row, const soap_calc_
             if ((t != 0 && t != 2) || (bound_only && !(fl & FL_BOUND))) continue;
             const double m = CX(m)[i], x = CX(dx)[i], y = CX(dy)[i], z = CX(dz)[i];
             const double u0 = CX(vx)[i], u1 = CX(vy)[i], u2 = CX(vz)[i];
+            if (cKap < 0) {
+                // spherical overdensities: the disc fractions only -- the sign of L_i about the particle's own component (as in rotation_pass)
+                const bool gas = t == 0;
+                const double a = u0 - (gas ? vc[0][0] : vc[1][0]), b = u1 - (gas ? vc[0][1] : vc[1][1]), w = u2 - (gas ? vc[0][2] : vc[1][2]);
+                const double h0 = gas ? hh[0][0] : hh[1][0], h1 = gas ? hh[0][1] : hh[1][1], h2 = gas ? hh[0][2] : hh[1][2];
+                const double l0 = m * (y * w - z * b), l1 = m * (z * a - x * w), l2 = m * (x * b - y * a);
+                const double Li = (l0 * h0 + l1 * h1) + l2 * h2;
+                const double mc = Li < 0.0 ? m : 0.0;
+                if (gas) sg[2] += mc; else ss[2] += mc;
+                continue;
+            }
             const double r2 = (x * x + y * y) + z * z;
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
@@ -1497,7 +1517,6 @@ __device__ __forceinline__ void small_rotation(GAS double *row, const soap_calc_
         const double p1 = wave_sum4(sg[0], sg[1], sg[2], ss[0]), p2 = wave_sum4(ss[1], ss[2], sb[0], sb[1]);
         const double t0 = rl64(p1, 0), t1 = rl64(p1, 16), t2 = rl64(p1, 32), t3 = rl64(p1, 48);
         const double t4 = rl64(p2, 0), t5 = rl64(p2, 16), t6 = rl64(p2, 32), t7 = rl64(p2, 48);
-        const double Ng = uni(crow[cNg]), Ns = uni(crow[cNs]);
         if (LANE == 0) {
             // a single member moves with its own centre-of-mass velocity: L = 0 exactly in the reference
             const double cnt[3] = {Ng, Ns, Ng + Ns};
