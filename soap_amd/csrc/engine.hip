@@ -643,6 +643,7 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
         for (int ts = 0; ts < SOAP_NTYPES; ts++) if (P.t[ts].n > 0) own_mass = fmax(own_mass, P.t[ts].mean_mass);
         own_mass *= (double)P.halo.nr_bound[h];
         double Rlo = -1.0, Rhi = R0, need = 0.0;
+        double wmax = 0.0;    // mass one thinned particle stands for (the largest over the types and thinning levels met)
         int nsamp = 0;
         for (int iter = 0; iter < 8; iter++) {
             // ---- thinned particles of the shell Rlo < r <= Rhi onto the ladder: the mesh rows of the sphere one after the other
@@ -710,6 +711,7 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 // (integer counts per type, added in type order: the same sum whatever order the particles came in)
                 binv += (double)ibin[lane] * (T.mean_mass * (coarse ? 1024.0 : 64.0));
                 bcnt += (double)ibin[lane];
+                wmax = fmax(wmax, T.mean_mass * (coarse ? 1024.0 : 64.0));
             }
             (void)cand;
             // ---- the loop on the ladder: lane k holds step k
@@ -721,7 +723,10 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
             // and adds the halo's own particles (a density that is too high ends the guessed loop later: a larger first sphere than
             // needed costs a little, a smaller one a rebuild -- a handful of samples at the inner steps used to read as "every threshold
             // crossed at the first step", and 5 x R500 of such a crossing as the end of the loop)
-            M = own_mass + M * (1.0 + 2.0 / sqrt(fmax(C, 1.0)));
+            // (... of a Poisson count: C + 2 sqrt(C) + 2 samples -- NO sample inside a step says "fewer than about two", not "none": a central of
+            // 56 particles in the envelope of a cluster, no thinned particle within 1.7 search radii, read as "below the target at the
+            // fourth step", its loop ends at 27 search radii and the giants' pipeline built it three times)
+            M = own_mass + M + (2.0 * sqrt(C) + 2.0) * wmax;
             dens[lane] = known ? M / (4.0 / 3.0 * M_PI * Rk * Rk * Rk) : 1e300;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (iter == 0) {
@@ -754,6 +759,12 @@ __global__ void __launch_bounds__(BLK) k_predict(const RunParams *Pp, double *r_
                 if (live && cd.kind == SOAP_CALC_SO_MULTIPLE) want = Rpar < 1e299 ? cd.radius * Rpar : 1e300;
                 if (live && cd.kind != SOAP_CALC_SO_DENSITY && cd.kind != SOAP_CALC_SO_MULTIPLE) want = cd.physical_radius_mpc;
             }
+#ifdef SOAP_DEBUG_PREDICT
+            if (h == SOAP_DEBUG_PREDICT) {
+                if (lane < 32) printf("iter %d lane %2d: Rk/Rs %8.3f dens/target %10.3g C %8.1f known %d | want/Rs %10.3g Rso/Rs %10.3g\n", iter, lane, Rk / Rs, dens[lane] / P.target_density, C, (int)known, want / Rs, Rso / Rs);
+                if (lane == 0) printf("iter %d: Rlo/Rs %.3f Rhi/Rs %.3f cap/Rs %.3f own_mass %.4g nsamp(lane0) %d cand %lld nr_bound %lld\n", iter, Rlo / Rs, Rhi / Rs, cap / Rs, own_mass, nsamp, cand, (long long)P.halo.nr_bound[h]);
+            }
+#endif
             for (int o = 32; o > 0; o >>= 1) want = fmax(want, __shfl_xor(want, o, 64));
             need = want;
             if (need <= Rhi) break;                 // the thinned sphere holds the end of the loop
