@@ -953,6 +953,7 @@ struct soap_engine {
     GBuild *d_gb = nullptr;        // scratch of the large halos' tile-parallel build
     size_t gb_count = 0;
     int *d_gints = nullptr;        // rows / tile tables of the large halos
+    std::vector<int> gints_host;   // ... packed for one upload
     size_t gints_count = 0;
     hipEvent_t ev_b[8][2] = {};    // giants' mode: property passes of every pipeline iteration
     int *d_gbins = nullptr;        // radial bins of the giants' build
@@ -2423,11 +2424,15 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                 const std::vector<int> *parts[12] = {&rows, &first_tile, &ntile, &first_gblock, &ngblock, &tile_li, &gblock_li, &first_sel, &nsel, &sel_li,
                                                      &bin_first, &nbinv};
                 int *dptr[12];
+                // (ONE upload: twelve copies of a few KB from pageable memory were 0.6 ms of a rank-of-8 pass, each a staging copy and a copy kernel that
+                // waits its turn behind the persistent groups)
+                std::vector<int> &packed = h->gints_host;
+                packed.clear();
                 for (int q = 0; q < 12; q++) {
-                    dptr[q] = d;
-                    HIPCHECK(hipMemcpyAsync(d, parts[q]->data(), parts[q]->size() * sizeof(int), hipMemcpyHostToDevice, cs));
-                    d += parts[q]->size();
+                    dptr[q] = d + packed.size();
+                    packed.insert(packed.end(), parts[q]->begin(), parts[q]->end());
                 }
+                HIPCHECK(hipMemcpyAsync(d, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, cs));
                 P.gb = h->d_gb; P.tile_li = dptr[5]; P.gblock_li = dptr[6]; P.sel_li = dptr[9]; P.gbins = h->d_gbins;
                 HIPCHECK(hipMemcpyAsync(h->d_params_pipe, &P, sizeof(RunParams), hipMemcpyHostToDevice, cs));
                 HIPCHECK(hipStreamWaitEvent(h->cls[0].stream, h->ev_p[1], 0));   // (class 0 reads the same parameter block: upload first)
