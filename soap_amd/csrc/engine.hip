@@ -2496,6 +2496,19 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
                             fprintf(stderr, "\n");
                         }
             }
+            if (trace) {
+                // who is built again, and how far the guess was off
+                std::vector<double> h_search0(n), h_read0(n);
+                std::vector<int> h_central(n);
+                (void)hipMemcpy(h_search0.data(), h->d_search, n * 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h_read0.data(), h->d_read, n * 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h_central.data(), h->d_central, n * 4, hipMemcpyDeviceToHost);
+                for (int k = 0; k < 3; k++)
+                    for (int i : todo[k])
+                        if (state[i] == PIPE_NEED_SUPERSET)
+                            fprintf(stderr, "[soap_engine] pipeline iteration %d: row %d (estimate %lld, bound %lld, guess %.4g x search radius) is built again out to %.4g x (central %d, read radius %.4g x, search radius %.4g)\n", iter, i, est[i],
+                                    h->h_nrbound[i], h->h_first[i] > 0.0 ? h->h_first[i] / h_search0[i] : 0.0, rbuild[i] / h_search0[i], h_central[i], h_read0[i] / h_search0[i], h_search0[i]);
+            }
             // stage 3 for the halos whose loop finished
             std::vector<int> fin[3], rest[3];
             for (int k = 0; k < 3; k++)
