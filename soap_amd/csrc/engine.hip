@@ -2161,9 +2161,14 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     if (giants) {
         // the pipeline works with the resources of the 1024-thread class only: the other two classes are busy with
         // the single-kernel path
+        // (not a giant: a halo of a few dozen particles whose first sphere overlaps the mesh cells of a cluster core -- 1e5 candidates to look at,
+        // a few hundred to keep -- and for which the radius guess expects no large sphere either.  Streaming its candidates is a millisecond on 256
+        // threads; in the pipeline it is a slice of the tile kernels and, when its loop runs past the default first superset, a whole second
+        // iteration for one row: rank of 8)
+        auto dwarf = [&](int i) { return !(h->h_first[i] > 0.0) && h->h_nrbound[i] * 64 < est[i]; };
         std::vector<int> big;
         for (int k = 0; k < 3; k++) {
-            for (int i : todo[k]) (est[i] > nb_giant ? big : early[k]).push_back(i);
+            for (int i : todo[k]) ((est[i] > nb_giant && !dwarf(i)) ? big : early[k]).push_back(i);
             todo[k].clear();
         }
         std::sort(big.begin(), big.end(), [&](int x, int y) { return est[x] != est[y] ? est[x] > est[y] : x < y; });
