@@ -1269,11 +1269,13 @@ __device__ __attribute__((noinline)) void small_inertia(GAS double *row, int kin
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the half-mass radii and masses of the rows were written by other lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- this lane's state
+    // (groups 0..7 hold the iterative states; the fixed-sphere tensor of the same calculation and weighting IS the tensor of their first
+    // iteration -- same sphere, same particles inside it, the same sums -- and is handed out with it: lanes of groups 8..15 idle)
     const int g = LANE & 15, r4 = LANE >> 4;
-    const int mode = g >> 3;                       // 0: iterative (groups 0..7), 1: fixed sphere (groups 8..15)
+    const int mode = 0;
     const int o = 2 * (g & 7) + (r4 >> 1);         // ordinal of the calculation among those with tensors
     const bool reduced = r4 & 1;
-    const bool mine = o < nic;
+    const bool mine = o < nic && g < 8;
     int c = 0;
     {
         unsigned long long mm = imask;
@@ -1302,7 +1304,8 @@ __device__ __attribute__((noinline)) void small_inertia(GAS double *row, int kin
     const int sflags = (bound_only ? 1 : 0) | (reduced ? 2 : 0);
     double ev0 = 1.0, ev1 = 1.0, ev2 = 1.0, q = 1000.0;
     double T[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    bool active = mine && has, valid = true;
+    double T0[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // the first iteration's tensor: the fixed-sphere one
+    bool active = mine && has, valid = true, valid0 = true;
     {
         double *S = g_W.it_par[LANE];
         for (int k = 0; k < 9; k++) S[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -1409,14 +1412,16 @@ __device__ __attribute__((noinline)) void small_inertia(GAS double *row, int kin
                 if (q == 0.0) { for (int k = 0; k < 6; k++) T[k] = 0.0; active = false; }   // :127-129
             }
         }
+        if (iter == 0) { for (int k = 0; k < 6; k++) T0[k] = T[k]; valid0 = valid; }
         WSYNC();
     }
     // columns: mode * 12 + reduced * 6; the dark matter tensors of a dark-matter-only chunk are the total ones
     if (mine) {
         for (int k = 0; k < 6; k++) {
-            const double val = (valid && has) ? T[k] : 0.0;
+            const double val = (valid && has) ? T[k] : 0.0, val0 = (valid0 && has) ? T0[k] : 0.0;
             row[out + k] = val;
-            if (has) row[out + 24 + k] = val;
+            row[out + 12 + k] = val0;
+            if (has) { row[out + 24 + k] = val; row[out + 36 + k] = val0; }
         }
     }
 }
