@@ -968,7 +968,7 @@ struct soap_engine {
     long long n_pipeline = 0, n_single = 0, n_small_escalated = 0;
     // timing
     double ms_halo = -1, ms_mesh = -1, ms_reorder = -1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_in = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_in = nullptr, ev_zero = nullptr;
     // staging that returned with its last kernels still in flight (on_device = 2): completed -- synchronised, checked, timed, its
     // temporaries released -- by the next call that needs the mesh (finish_stage)
     bool stage_pending = false;
@@ -1092,6 +1092,7 @@ static int32_t create_resources(soap_engine *h) {
     HIPCHECK(hipEventCreate(&h->ev1));
     HIPCHECK(hipEventCreate(&h->ev2));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_zero, hipEventDisableTiming));
     HIPCHECK(hipMalloc((void **)&h->d_queue, sizeof(unsigned)));
     // one stream per thread-group class, on distinct priority levels where the device offers three:
     // streams of equal priority may be mapped onto the same hardware queue (and then serialise), streams of
@@ -1664,7 +1665,10 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     HIPCHECK(h->pool.alloc((void **)&h->d_table, h->table_bytes));
     HIPCHECK(h->pool.alloc((void **)&h->d_calcs, h->calcs_bytes));
     HIPCHECK(h->pool.alloc((void **)&h->d_coloff, h->coloff_bytes));
-    // (the table is not cleared here: every workgroup zeroes the row of a halo before it starts on it)
+    // the table is cleared ONCE, here, on a stream that is idle between runs, while the estimate kernels work (0.15 ms for the 766 MB of the C3
+    // list at HBM speed): no group zeroes a row from the inside (957 columns per halo: 15 stores per lane of a small halo's wave, before its first load)
+    HIPCHECK(hipMemsetAsync(h->d_table, 0, h->table_bytes, h->team_stream));
+    HIPCHECK(hipEventRecord(h->ev_zero, h->team_stream));
     HIPCHECK(hipMemcpyAsync(h->d_calcs, calcs, (size_t)n_calcs * sizeof(soap_calc_desc), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(h->d_coloff, coloff.data(), (size_t)n_calcs * 4, hipMemcpyHostToDevice, st));
 
@@ -1942,6 +1946,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
             while (caps[2] < cap_max && caps[2] < 4 * need && groups[2] / 2 >= std::max<long long>(16, std::min<long long>(n_top, split_large ? 256 : 64))) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
             while (caps[2] < cap_max && caps[2] < need + need / 4) { caps[2] = std::min(caps[2] * 2, cap_max); groups[2] = std::max(1, groups[2] / 2); }
         }
+        HIPCHECK(hipStreamWaitEvent(st, h->ev_zero, 0));   // (the cleared table)
         HIPCHECK(hipEventRecord(h->ev_p[0], st));
         for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
         const int rc = launch_single(early, h->ev_p[0], false);
@@ -2138,6 +2143,7 @@ int32_t soap_engine_run(soap_engine *h, const soap_calc_desc *calcs, int32_t n_c
     h->n_gbuild = 0;
     if (trace) { fprintf(stderr, "[soap_engine] ev_p0=%p pipeline=%d st=%p\n", (void *)h->ev_p[0], (int)pipeline, (void *)st); fflush(stderr); }
     if (!early_big) {
+        HIPCHECK(hipStreamWaitEvent(st, h->ev_zero, 0));   // (the cleared table)
         HIPCHECK(hipEventRecord(h->ev_p[0], st));
         for (int k = 0; k < 3; k++) { h->cls[k].ms = 0.0; h->cls[k].nh = 0; }
     }

@@ -1814,7 +1814,7 @@ SOAP_CAT4(k_small, SNS, SVAR, )(const RunParams *Pp, unsigned *queue, const int 
         WSYNC();
         const bool use_target = central == 1 && target_density > 0.0;
         GAS double *row = table + hrow * ncols;
-        for (long long k = LANE; k < ncols; k += 64) row[k] = 0.0;   // columns nobody writes stay zero
+        // (columns nobody writes stay zero: the table was cleared by one memset when the run began; nothing is written before the property passes)
         if (dbg_stop == 8) { if (LANE == 0) h_status[hrow] = SOAP_HALO_OK; continue; }
 #ifdef SMALL_STUB8
         { if (LANE == 0) h_status[hrow] = SOAP_HALO_OK; continue; }
