@@ -1243,6 +1243,7 @@ int32_t soap_engine_destroy(soap_engine *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_zero) (void)hipEventDestroy(h->ev_zero);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     probe("events");
     delete h;
